@@ -1,0 +1,175 @@
+/* libreef_msm.so -- MI355X (gfx950) backend for the Pasta-curve MSM hot path of eniac/Reef.
+ *
+ * C ABI only: plain pointers and sizes, no C++ / torch types.  Every entry point names the
+ * reference interface it replaces (paths relative to the Reef repository).  Symbols marked
+ * [R] belong to crates that are NOT vendored in the reference tree (nova-snark @ sga001/Nova,
+ * fil_pasta_curves 0.5.2, pasta-msm; Cargo.toml:12,14) -- their layouts are isolated in this
+ * header so they can be corrected in one place.
+ *
+ * Data layouts (fil_pasta_curves `repr-c`, Cargo.toml:14) [R]:
+ *   reef_fe        4 x u64 little-endian limbs, Montgomery form (R = 2^256), fully reduced
+ *   reef_affine    {x, y}      64 B, identity = (0, 0)                 (EpAffine / EqAffine)
+ *   reef_jacobian  {x, y, z}   96 B, identity has z = 0                (Ep / Eq)
+ * Scalars of Pallas are Fq elements, scalars of Vesta are Fp elements (the cycle).
+ *
+ * Error behaviour: the reference treats every failure as a panic (framework.rs:683,702).  The
+ * pasta-msm compatible symbols return void and abort() with a message on any error; the handle
+ * API returns a reef_status and records a message retrievable with reef_last_error().  There is
+ * no CPU fallback: without a usable gfx950 device every call fails loudly.
+ *
+ * Threading: all entry points are re-entrant.  A reef_msm_ctx serialises the calls made on it
+ * (it owns one HIP stream and one workspace); use one ctx (or clone) per concurrent caller.
+ */
+#ifndef REEF_MSM_H
+#define REEF_MSM_H
+
+#include <stdbool.h>
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct { uint64_t l[4]; } reef_fe;
+typedef struct { reef_fe x, y; } reef_affine;
+typedef struct { reef_fe x, y, z; } reef_jacobian;
+
+enum { REEF_PALLAS = 0, REEF_VESTA = 1 };
+enum { REEF_HOST = 0, REEF_DEVICE = 1 }; /* where a buffer lives */
+
+typedef enum {
+    REEF_OK = 0,
+    REEF_ERR_ARG = 1,    /* bad argument (null pointer, size mismatch, unknown curve) */
+    REEF_ERR_HIP = 2,    /* HIP runtime error (message in reef_last_error) */
+    REEF_ERR_NO_GPU = 3, /* no gfx950 device visible */
+    REEF_ERR_OOM = 4
+} reef_status;
+
+/* ---------------------------------------------------------------------------------------------
+ * (1) pasta-msm drop-in symbols [R].
+ * Replaces: `extern "C" mult_pippenger_pallas/vesta` declared by the pasta-msm crate and reached
+ * from nova-snark's `Group::vartime_multiscalar_mul` (provider/pasta.rs) for every commitment:
+ * src/backend/framework.rs:668 (RecursiveSNARK::prove_step), :695 (CompressedSNARK::prove),
+ * src/backend/commitment.rs:187,350,361,371,383,422,430.
+ * Stateless: nothing is retained; bases are uploaded per call.  `is_mont` = scalars are in
+ * Montgomery form (what the Rust wrapper passes).  abort()s on error.
+ * ------------------------------------------------------------------------------------------- */
+void mult_pippenger_pallas(reef_jacobian *out, const reef_affine *points, size_t npoints,
+                           const reef_fe *scalars, bool is_mont);
+void mult_pippenger_vesta(reef_jacobian *out, const reef_affine *points, size_t npoints,
+                          const reef_fe *scalars, bool is_mont);
+
+/* ---------------------------------------------------------------------------------------------
+ * (2) Resident-key handle API.
+ * Replaces: nova-snark `CommitmentGens<G>` [R] as held inside PublicParams / HyraxPC for the
+ * life of a proof (src/backend/framework.rs:45,134,297-303; src/backend/commitment.rs:176-186).
+ * The bases are uploaded once; with `precompute` the key also stores 2^(c*G*j)-shifted copies so
+ * that several Pippenger windows share one bucket set (HBM is 288 GB; a 2^20-point key with
+ * 16 tables is 1 GiB).
+ * ------------------------------------------------------------------------------------------- */
+typedef struct reef_msm_ctx reef_msm_ctx;
+
+typedef struct {
+    uint32_t window_bits;   /* Pippenger window c; 0 = choose from n */
+    uint32_t bucket_groups; /* G: 0 = one group per window (no precompute); 1 = full precompute
+                               (all windows share one bucket set); otherwise windows w and w'
+                               share buckets iff w % G == w' % G */
+    uint32_t chunk;         /* sorted entries per accumulation thread (L0); 0 = default */
+    uint32_t segment;       /* buckets per bucket-reduce thread; 0 = default */
+    int32_t device;         /* HIP device ordinal; -1 = current device */
+    uint32_t reserved[3];
+} reef_msm_opts;
+
+reef_status reef_msm_ctx_create(reef_msm_ctx **out, int curve, const reef_affine *bases, size_t n,
+                                int bases_loc, const reef_msm_opts *opts /* may be NULL */);
+/* A second handle on the same resident key with its own stream and workspace (for callers that
+ * issue MSMs from several threads, e.g. nova's rayon workers inside ipa_pc). */
+reef_status reef_msm_ctx_clone(reef_msm_ctx **out, reef_msm_ctx *src);
+void reef_msm_ctx_destroy(reef_msm_ctx *ctx);
+/* Block until everything enqueued on the ctx's stream has finished. */
+reef_status reef_msm_ctx_sync(reef_msm_ctx *ctx);
+/* The ctx's hipStream_t (as void*), e.g. to order work of a torch/RCCL stream after it. */
+void *reef_msm_ctx_stream(reef_msm_ctx *ctx);
+
+/* K1: out = sum_{i<n} scalars[i] * bases[i], n <= key length.
+ * Replaces Group::vartime_multiscalar_mul / CE::commit without blind [R] (call sites above).
+ * With out_loc == REEF_DEVICE the call only enqueues work (no host sync). */
+reef_status reef_msm(reef_msm_ctx *ctx, const reef_fe *scalars, size_t n, int scalars_loc,
+                     bool is_mont, reef_jacobian *out, int out_loc);
+
+/* K2: rows independent MSMs over the same first row_len bases, plus an optional Pedersen blind:
+ *   out[r] = sum_j scalars[r*row_len + j] * bases[j]  (+ blinds[r] * h   if blinds != NULL)
+ * Replaces HyraxPC::commit(&poly) [R] at src/backend/commitment.rs:187 (L = 2^(l/2) rows of
+ * R = 2^(l - l/2) symbols each, src/backend/commitment.rs:173-174) and CE::commit with blind
+ * (commitment.rs:350,361,422,430) when rows == 1.  `max_scalar_bits` bounds the canonical
+ * scalars (e.g. 8 for ASCII symbols, 3 for DNA; framework.rs:978-1011); 0 = measure on device.
+ * blinds/h live where scalars live. */
+reef_status reef_msm_rows(reef_msm_ctx *ctx, const reef_fe *scalars, size_t rows, size_t row_len,
+                          int scalars_loc, bool is_mont, uint32_t max_scalar_bits,
+                          const reef_fe *blinds, const reef_affine *h, reef_jacobian *out,
+                          int out_loc);
+
+/* ---------------------------------------------------------------------------------------------
+ * (3) Stateless helpers around the MSMs.
+ * ------------------------------------------------------------------------------------------- */
+/* K3: out[i] = w1*gens[i] + w2*gens[half+i], i < half, affine out.
+ * Replaces CommitmentGens::fold [R] as used by ipa_pc::InnerProductArgument::prove inside
+ * CompressedSNARK::prove (src/backend/framework.rs:695).  w1, w2: canonical (non-Montgomery)
+ * 32-byte little-endian scalars on the host. */
+reef_status reef_fold(int curve, const reef_affine *gens, size_t half, int loc, const reef_fe *w1,
+                      const reef_fe *w2, reef_affine *out);
+
+/* K4: batch Jacobian -> affine and/or 32-byte compressed encoding (LE canonical x, y parity in
+ * bit 255, identity = zeros).  Replaces Commitment::compress / to_affine [R]
+ * (src/backend/commitment.rs:195,351,365,425,427,431).  Either output may be NULL. */
+reef_status reef_normalize(int curve, const reef_jacobian *in, size_t n, int loc, reef_affine *out_affine,
+                           uint8_t *out_compressed);
+
+/* Sum of n Jacobian points (multi-GPU: combine the per-rank partial MSMs after an all-gather). */
+reef_status reef_sum_points(int curve, const reef_jacobian *in, size_t n, int loc, reef_jacobian *out);
+
+/* Deterministic synthetic inputs, generated on the device (bench / tests; no file I/O):
+ * bases B_i = (k0 + i*d)*G with G = (-1, 2); scalars from a SplitMix64 stream
+ * (kind 0 uniform, 1 witness-like 70/20/10 mix, 2 uniform below small_bound). */
+reef_status reef_gen_bases(int curve, uint64_t k0, uint64_t d, size_t n, reef_affine *out, int loc);
+reef_status reef_gen_scalars(int curve, uint64_t seed, int kind, uint64_t small_bound, size_t n,
+                             bool to_mont, reef_fe *out, int loc);
+
+/* ---------------------------------------------------------------------------------------------
+ * (4) Runtime plumbing.
+ * ------------------------------------------------------------------------------------------- */
+int reef_device_count(void);
+reef_status reef_set_device(int ordinal);
+reef_status reef_device_sync(void);
+void *reef_device_alloc(size_t bytes);                 /* hipMalloc; NULL on failure */
+void reef_device_free(void *p);
+reef_status reef_memcpy(void *dst, const void *src, size_t bytes, int dst_loc, int src_loc);
+const char *reef_last_error(void);                     /* thread-local message of the last failure */
+const char *reef_version(void);
+
+/* Timing of the last reef_msm / reef_msm_rows on this ctx, measured with HIP events on the ctx's
+ * stream (valid after a sync): total and the accumulation kernel alone, in milliseconds. */
+reef_status reef_msm_ctx_last_timing(reef_msm_ctx *ctx, float *total_ms, float *accumulate_ms);
+/* Plan actually used by the ctx: window bits, windows, bucket groups, tables. */
+reef_status reef_msm_ctx_plan(reef_msm_ctx *ctx, uint32_t *c, uint32_t *windows, uint32_t *groups,
+                              uint32_t *tables);
+
+/* Plan the engine would choose for an n-point key with the given options (pure host logic; works
+ * without a GPU): window bits c, windows W = ceil(256/c), bucket groups G, tables T = ceil(W/G). */
+reef_status reef_msm_plan_for(size_t n, uint32_t window_bits, uint32_t bucket_groups, uint32_t *c,
+                              uint32_t *windows, uint32_t *groups, uint32_t *tables);
+
+/* Device self-tests used by the parity suite (element-wise kernels over n inputs, HOST buffers).
+ * field: 0 Fp, 1 Fq.  op: 0 mul 1 add 2 sub 3 inv 4 to_mont 5 from_mont 6 neg 7 sqr. */
+reef_status reef_test_field_op(int field, int op, const reef_fe *a, const reef_fe *b, reef_fe *out, size_t n);
+/* op: 0 mixed add P+Q, 1 general add, 2 double P, 3 k*P (k canonical in kbuf). */
+reef_status reef_test_ec_op(int curve, int op, const reef_affine *p, const reef_affine *q, const reef_fe *k,
+                            reef_jacobian *out, size_t n);
+/* Field-multiplication throughput probe: returns Montgomery products per second. */
+reef_status reef_bench_fmul(int field, uint32_t iters, double *products_per_s);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* REEF_MSM_H */

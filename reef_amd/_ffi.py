@@ -1,0 +1,106 @@
+"""ctypes binding of libreef_msm.so (the C ABI declared in include/reef_msm.h).
+
+The library is built in-tree (reef_amd/_lib/libreef_msm.so) by `build()`; nothing here falls
+back to a CPU implementation: if the shared object is missing, loading raises.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+import subprocess
+from ctypes import POINTER, c_bool, c_char_p, c_double, c_float, c_int, c_int32, c_size_t, c_uint8, c_uint32, c_uint64, c_void_p
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(_HERE, "csrc")
+LIB_PATH = os.path.join(_HERE, "_lib", "libreef_msm.so")
+HEADER = os.path.join(os.path.dirname(_HERE), "include", "reef_msm.h")
+
+REEF_HOST, REEF_DEVICE = 0, 1
+PALLAS, VESTA = 0, 1
+STATUS_NAMES = {0: "REEF_OK", 1: "REEF_ERR_ARG", 2: "REEF_ERR_HIP", 3: "REEF_ERR_NO_GPU", 4: "REEF_ERR_OOM"}
+
+
+class ReefError(RuntimeError):
+    def __init__(self, status: int, message: str):
+        super().__init__(f"{STATUS_NAMES.get(status, status)}: {message}")
+        self.status = status
+
+
+class MsmOpts(ctypes.Structure):
+    _fields_ = [("window_bits", c_uint32), ("bucket_groups", c_uint32), ("chunk", c_uint32), ("segment", c_uint32),
+                ("device", c_int32), ("reserved", c_uint32 * 3)]
+
+
+def build(force: bool = False, jobs: int = 3) -> str:
+    """Compile every HIP source for gfx950 (hipcc cross-compiles without a GPU)."""
+    cmd = ["make", "-C", CSRC, f"-j{jobs}"]
+    if force:
+        cmd.append("-B")
+    subprocess.check_call(cmd, stdout=subprocess.DEVNULL)
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError("build finished but %s is missing" % LIB_PATH)
+    return LIB_PATH
+
+
+_lib = None
+
+
+def load() -> ctypes.CDLL:
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(f"{LIB_PATH} not built: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                           "(there is no CPU fallback for the MSM path)")
+    lib = ctypes.CDLL(LIB_PATH)
+    vp = c_void_p
+    sig = {
+        "mult_pippenger_pallas": (None, [vp, vp, c_size_t, vp, c_bool]),
+        "mult_pippenger_vesta": (None, [vp, vp, c_size_t, vp, c_bool]),
+        "reef_msm_ctx_create": (c_int, [POINTER(vp), c_int, vp, c_size_t, c_int, POINTER(MsmOpts)]),
+        "reef_msm_ctx_clone": (c_int, [POINTER(vp), vp]),
+        "reef_msm_ctx_destroy": (None, [vp]),
+        "reef_msm_ctx_sync": (c_int, [vp]),
+        "reef_msm_ctx_stream": (vp, [vp]),
+        "reef_msm": (c_int, [vp, vp, c_size_t, c_int, c_bool, vp, c_int]),
+        "reef_msm_rows": (c_int, [vp, vp, c_size_t, c_size_t, c_int, c_bool, c_uint32, vp, vp, vp, c_int]),
+        "reef_fold": (c_int, [c_int, vp, c_size_t, c_int, vp, vp, vp]),
+        "reef_normalize": (c_int, [c_int, vp, c_size_t, c_int, vp, vp]),
+        "reef_sum_points": (c_int, [c_int, vp, c_size_t, c_int, vp]),
+        "reef_gen_bases": (c_int, [c_int, c_uint64, c_uint64, c_size_t, vp, c_int]),
+        "reef_gen_scalars": (c_int, [c_int, c_uint64, c_int, c_uint64, c_size_t, c_bool, vp, c_int]),
+        "reef_device_count": (c_int, []),
+        "reef_set_device": (c_int, [c_int]),
+        "reef_device_sync": (c_int, []),
+        "reef_device_alloc": (vp, [c_size_t]),
+        "reef_device_free": (None, [vp]),
+        "reef_memcpy": (c_int, [vp, vp, c_size_t, c_int, c_int]),
+        "reef_last_error": (c_char_p, []),
+        "reef_version": (c_char_p, []),
+        "reef_msm_ctx_last_timing": (c_int, [vp, POINTER(c_float), POINTER(c_float)]),
+        "reef_msm_ctx_plan": (c_int, [vp, POINTER(c_uint32), POINTER(c_uint32), POINTER(c_uint32), POINTER(c_uint32)]),
+        "reef_msm_plan_for": (c_int, [c_size_t, c_uint32, c_uint32, POINTER(c_uint32), POINTER(c_uint32), POINTER(c_uint32),
+                                      POINTER(c_uint32)]),
+        "reef_test_field_op": (c_int, [c_int, c_int, vp, vp, vp, c_size_t]),
+        "reef_test_ec_op": (c_int, [c_int, c_int, vp, vp, vp, vp, c_size_t]),
+        "reef_bench_fmul": (c_int, [c_int, c_uint32, POINTER(c_double)]),
+    }
+    for name, (res, args) in sig.items():
+        fn = getattr(lib, name)  # AttributeError if the ABI lost a symbol: fail loudly
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(status: int) -> None:
+    if status != 0:
+        raise ReefError(status, load().reef_last_error().decode(errors="replace"))
+
+
+def declared_symbols() -> list[str]:
+    """Function names declared in include/reef_msm.h (used by the ABI export test)."""
+    import re
+    text = open(HEADER).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b((?:reef_|mult_pippenger_)\w+)\s*\(", text)))

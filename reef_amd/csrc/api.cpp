@@ -1,0 +1,230 @@
+// C ABI of libreef_msm.so (see include/reef_msm.h).  Thin dispatch onto the per-curve engines;
+// no arithmetic here and no CPU fallback: without a gfx950 device every call fails loudly.
+#include <stdarg.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <memory>
+#include <mutex>
+
+#include "common.h"
+
+namespace reef {
+
+static thread_local char g_err[512] = "";
+
+void set_error(const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof g_err, fmt, ap);
+    va_end(ap);
+}
+
+static const CurveVTable *vt(int curve) {
+    if (curve == REEF_PALLAS) return pallas_vtable();
+    if (curve == REEF_VESTA) return vesta_vtable();
+    set_error("unknown curve %d", curve);
+    return nullptr;
+}
+
+static reef_status require_gpu() {
+    static std::once_flag once;
+    static reef_status st = REEF_OK;
+    static char msg[256];
+    std::call_once(once, [] {
+        int n = 0;
+        hipError_t e = hipGetDeviceCount(&n);
+        if (e != hipSuccess || n == 0) {
+            snprintf(msg, sizeof msg, "no HIP device visible (%s)", e == hipSuccess ? "count = 0" : hipGetErrorString(e));
+            st = REEF_ERR_NO_GPU;
+            return;
+        }
+        hipDeviceProp_t prop;
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        e = hipGetDeviceProperties(&prop, dev);
+        if (e != hipSuccess) { snprintf(msg, sizeof msg, "hipGetDeviceProperties: %s", hipGetErrorString(e)); st = REEF_ERR_HIP; return; }
+        if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+            snprintf(msg, sizeof msg, "device %d is %s; libreef_msm.so carries gfx950 code only", dev, prop.gcnArchName);
+            st = REEF_ERR_NO_GPU;
+        }
+    });
+    if (st != REEF_OK) set_error("%s", msg);
+    return st;
+}
+
+}  // namespace reef
+
+using namespace reef;
+
+struct reef_msm_ctx {
+    int curve;
+    void *impl;
+};
+
+extern "C" {
+
+const char *reef_last_error(void) { return g_err; }
+const char *reef_version(void) { return "reef_msm 0.1 (gfx950)"; }
+
+int reef_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+reef_status reef_set_device(int ordinal) {
+    REEF_HIP_TRY(hipSetDevice(ordinal));
+    return REEF_OK;
+}
+reef_status reef_device_sync(void) {
+    REEF_HIP_TRY(hipDeviceSynchronize());
+    return REEF_OK;
+}
+void *reef_device_alloc(size_t bytes) {
+    void *p = nullptr;
+    hipError_t e = hipMalloc(&p, bytes ? bytes : 16);
+    if (e != hipSuccess) { set_error("hipMalloc(%zu): %s", bytes, hipGetErrorString(e)); return nullptr; }
+    return p;
+}
+void reef_device_free(void *p) {
+    if (p) (void)hipFree(p);
+}
+reef_status reef_memcpy(void *dst, const void *src, size_t bytes, int dst_loc, int src_loc) {
+    hipMemcpyKind k = dst_loc == REEF_DEVICE ? (src_loc == REEF_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice)
+                                             : (src_loc == REEF_DEVICE ? hipMemcpyDeviceToHost : hipMemcpyHostToHost);
+    REEF_HIP_TRY(hipMemcpy(dst, src, bytes, k));
+    return REEF_OK;
+}
+
+reef_status reef_msm_ctx_create(reef_msm_ctx **out, int curve, const reef_affine *bases, size_t n, int bases_loc,
+                                const reef_msm_opts *opts) {
+    if (!out) { set_error("null argument"); return REEF_ERR_ARG; }
+    const CurveVTable *v = vt(curve);
+    if (!v) return REEF_ERR_ARG;
+    REEF_TRY(require_gpu());
+    void *impl = nullptr;
+    REEF_TRY(v->ctx_create(&impl, bases, n, bases_loc, opts));
+    *out = new reef_msm_ctx{curve, impl};
+    return REEF_OK;
+}
+reef_status reef_msm_ctx_clone(reef_msm_ctx **out, reef_msm_ctx *src) {
+    if (!out || !src) { set_error("null argument"); return REEF_ERR_ARG; }
+    void *impl = nullptr;
+    REEF_TRY(vt(src->curve)->ctx_clone(&impl, src->impl));
+    *out = new reef_msm_ctx{src->curve, impl};
+    return REEF_OK;
+}
+void reef_msm_ctx_destroy(reef_msm_ctx *ctx) {
+    if (!ctx) return;
+    vt(ctx->curve)->ctx_destroy(ctx->impl);
+    delete ctx;
+}
+reef_status reef_msm_ctx_sync(reef_msm_ctx *ctx) {
+    if (!ctx) { set_error("null argument"); return REEF_ERR_ARG; }
+    return vt(ctx->curve)->ctx_sync(ctx->impl);
+}
+void *reef_msm_ctx_stream(reef_msm_ctx *ctx) { return ctx ? vt(ctx->curve)->ctx_stream(ctx->impl) : nullptr; }
+reef_status reef_msm_ctx_last_timing(reef_msm_ctx *ctx, float *total_ms, float *accumulate_ms) {
+    if (!ctx) { set_error("null argument"); return REEF_ERR_ARG; }
+    return vt(ctx->curve)->ctx_timing(ctx->impl, total_ms, accumulate_ms);
+}
+reef_status reef_msm_ctx_plan(reef_msm_ctx *ctx, uint32_t *c, uint32_t *windows, uint32_t *groups, uint32_t *tables) {
+    if (!ctx) { set_error("null argument"); return REEF_ERR_ARG; }
+    return vt(ctx->curve)->ctx_plan(ctx->impl, c, windows, groups, tables);
+}
+
+reef_status reef_msm(reef_msm_ctx *ctx, const reef_fe *scalars, size_t n, int scalars_loc, bool is_mont, reef_jacobian *out,
+                     int out_loc) {
+    if (!ctx) { set_error("null argument"); return REEF_ERR_ARG; }
+    return vt(ctx->curve)->msm(ctx->impl, scalars, n, scalars_loc, is_mont, out, out_loc);
+}
+reef_status reef_msm_rows(reef_msm_ctx *ctx, const reef_fe *scalars, size_t rows, size_t row_len, int scalars_loc, bool is_mont,
+                          uint32_t max_scalar_bits, const reef_fe *blinds, const reef_affine *h, reef_jacobian *out, int out_loc) {
+    if (!ctx) { set_error("null argument"); return REEF_ERR_ARG; }
+    return vt(ctx->curve)->msm_rows(ctx->impl, scalars, rows, row_len, scalars_loc, is_mont, max_scalar_bits, blinds, h, out, out_loc);
+}
+
+reef_status reef_msm_plan_for(size_t n, uint32_t window_bits, uint32_t bucket_groups, uint32_t *c, uint32_t *windows,
+                              uint32_t *groups, uint32_t *tables) {
+    return pallas_vtable()->plan_for(n, window_bits, bucket_groups, c, windows, groups, tables);
+}
+
+#define STATELESS_PROLOGUE(curve)          \
+    const CurveVTable *v = vt(curve);      \
+    if (!v) return REEF_ERR_ARG;           \
+    REEF_TRY(require_gpu())
+
+reef_status reef_fold(int curve, const reef_affine *gens, size_t half, int loc, const reef_fe *w1, const reef_fe *w2,
+                      reef_affine *out) {
+    STATELESS_PROLOGUE(curve);
+    return v->fold(gens, half, loc, w1, w2, out);
+}
+reef_status reef_normalize(int curve, const reef_jacobian *in, size_t n, int loc, reef_affine *out_affine, uint8_t *out_compressed) {
+    STATELESS_PROLOGUE(curve);
+    return v->normalize(in, n, loc, out_affine, out_compressed);
+}
+reef_status reef_sum_points(int curve, const reef_jacobian *in, size_t n, int loc, reef_jacobian *out) {
+    STATELESS_PROLOGUE(curve);
+    return v->sum_points(in, n, loc, out);
+}
+reef_status reef_gen_bases(int curve, uint64_t k0, uint64_t d, size_t n, reef_affine *out, int loc) {
+    STATELESS_PROLOGUE(curve);
+    return v->gen_bases(k0, d, n, out, loc);
+}
+reef_status reef_gen_scalars(int curve, uint64_t seed, int kind, uint64_t small_bound, size_t n, bool to_mont, reef_fe *out,
+                             int loc) {
+    STATELESS_PROLOGUE(curve);
+    return v->gen_scalars(seed, kind, small_bound, n, to_mont, out, loc);
+}
+reef_status reef_test_field_op(int field, int op, const reef_fe *a, const reef_fe *b, reef_fe *out, size_t n) {
+    STATELESS_PROLOGUE(field);  // coordinate field of curve `field`
+    return v->test_field_op(op, a, b, out, n);
+}
+reef_status reef_test_ec_op(int curve, int op, const reef_affine *p, const reef_affine *q, const reef_fe *k, reef_jacobian *out,
+                            size_t n) {
+    STATELESS_PROLOGUE(curve);
+    return v->test_ec_op(op, p, q, k, out, n);
+}
+reef_status reef_bench_fmul(int field, uint32_t iters, double *products_per_s) {
+    STATELESS_PROLOGUE(field);
+    if (!products_per_s) { set_error("null argument"); return REEF_ERR_ARG; }
+    return v->bench_fmul(iters, products_per_s);
+}
+
+// ---- pasta-msm drop-in symbols: stateless, abort on failure (the Rust side panics on error).
+// A per-thread context is kept so that repeated calls reuse the workspace; the bases are
+// re-uploaded on every call, as the reference semantics (nothing retained) require.
+namespace {
+struct TlsCtx {
+    reef_msm_ctx *ctx[2] = {nullptr, nullptr};
+    ~TlsCtx() {
+        for (auto *c : ctx) reef_msm_ctx_destroy(c);
+    }
+};
+thread_local TlsCtx g_tls;
+
+static void pippenger(int curve, reef_jacobian *out, const reef_affine *points, size_t npoints, const reef_fe *scalars, bool is_mont) {
+    reef_status st;
+    reef_msm_ctx *&c = g_tls.ctx[curve];
+    if (!c) {
+        st = reef_msm_ctx_create(&c, curve, points, npoints, REEF_HOST, nullptr);
+    } else {
+        st = vt(curve)->ctx_rekey(c->impl, points, npoints, REEF_HOST);
+    }
+    if (st == REEF_OK) st = reef_msm(c, scalars, npoints, REEF_HOST, is_mont, out, REEF_HOST);
+    if (st != REEF_OK) {
+        fprintf(stderr, "libreef_msm: mult_pippenger_%s failed: %s\n", curve == REEF_PALLAS ? "pallas" : "vesta", reef_last_error());
+        abort();
+    }
+}
+}  // namespace
+
+void mult_pippenger_pallas(reef_jacobian *out, const reef_affine *points, size_t npoints, const reef_fe *scalars, bool is_mont) {
+    pippenger(REEF_PALLAS, out, points, npoints, scalars, is_mont);
+}
+void mult_pippenger_vesta(reef_jacobian *out, const reef_affine *points, size_t npoints, const reef_fe *scalars, bool is_mont) {
+    pippenger(REEF_VESTA, out, points, npoints, scalars, is_mont);
+}
+
+}  // extern "C"

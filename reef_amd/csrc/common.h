@@ -1,0 +1,75 @@
+// Host-side plumbing shared by the per-curve engines and the C ABI (not part of the ABI).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+#include "../../include/reef_msm.h"
+
+namespace reef {
+
+void set_error(const char *fmt, ...) __attribute__((format(printf, 1, 2)));
+
+#define REEF_HIP_TRY(expr)                                                                          \
+    do {                                                                                            \
+        hipError_t e_ = (expr);                                                                     \
+        if (e_ != hipSuccess) {                                                                     \
+            ::reef::set_error("%s: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__);  \
+            return e_ == hipErrorOutOfMemory ? REEF_ERR_OOM : REEF_ERR_HIP;                         \
+        }                                                                                           \
+    } while (0)
+
+#define REEF_TRY(expr)                          \
+    do {                                        \
+        reef_status s_ = (expr);                \
+        if (s_ != REEF_OK) return s_;           \
+    } while (0)
+
+// Grow-only device buffer (steady state performs no allocation).
+struct DevBuf {
+    void *p = nullptr;
+    size_t cap = 0;
+    reef_status ensure(size_t bytes) {
+        if (bytes <= cap) return REEF_OK;
+        if (p) { (void)hipFree(p); p = nullptr; cap = 0; }
+        size_t want = bytes + bytes / 8 + 256;
+        REEF_HIP_TRY(hipMalloc(&p, want));
+        cap = want;
+        return REEF_OK;
+    }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+    }
+    template <class T> T *as() const { return reinterpret_cast<T *>(p); }
+};
+
+// Per-curve entry points, implemented once per curve in kernels_<curve>.hip via engine.inc.
+struct CurveVTable {
+    reef_status (*ctx_create)(void **impl, const reef_affine *bases, size_t n, int loc, const reef_msm_opts *opts);
+    reef_status (*ctx_rekey)(void *impl, const reef_affine *bases, size_t n, int loc);
+    reef_status (*ctx_clone)(void **impl, void *src);
+    void (*ctx_destroy)(void *impl);
+    reef_status (*ctx_sync)(void *impl);
+    void *(*ctx_stream)(void *impl);
+    reef_status (*ctx_timing)(void *impl, float *total_ms, float *acc_ms);
+    reef_status (*ctx_plan)(void *impl, uint32_t *c, uint32_t *w, uint32_t *g, uint32_t *t);
+    reef_status (*msm)(void *impl, const reef_fe *scalars, size_t n, int loc, bool is_mont, reef_jacobian *out, int out_loc);
+    reef_status (*msm_rows)(void *impl, const reef_fe *scalars, size_t rows, size_t row_len, int loc, bool is_mont,
+                            uint32_t max_bits, const reef_fe *blinds, const reef_affine *h, reef_jacobian *out, int out_loc);
+    reef_status (*fold)(const reef_affine *gens, size_t half, int loc, const reef_fe *w1, const reef_fe *w2, reef_affine *out);
+    reef_status (*normalize)(const reef_jacobian *in, size_t n, int loc, reef_affine *out_aff, uint8_t *out_comp);
+    reef_status (*sum_points)(const reef_jacobian *in, size_t n, int loc, reef_jacobian *out);
+    reef_status (*gen_bases)(uint64_t k0, uint64_t d, size_t n, reef_affine *out, int loc);
+    reef_status (*gen_scalars)(uint64_t seed, int kind, uint64_t small_bound, size_t n, bool to_mont, reef_fe *out, int loc);
+    reef_status (*test_field_op)(int op, const reef_fe *a, const reef_fe *b, reef_fe *out, size_t n);  // coordinate field
+    reef_status (*test_ec_op)(int op, const reef_affine *p, const reef_affine *q, const reef_fe *k, reef_jacobian *out, size_t n);
+    reef_status (*bench_fmul)(uint32_t iters, double *per_s);
+    reef_status (*plan_for)(size_t n, uint32_t c_opt, uint32_t g_opt, uint32_t *c, uint32_t *w, uint32_t *g, uint32_t *t);
+};
+
+const CurveVTable *pallas_vtable();
+const CurveVTable *vesta_vtable();
+
+}  // namespace reef

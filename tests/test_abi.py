@@ -1,0 +1,56 @@
+"""The C-ABI library loads and exports every symbol include/reef_msm.h declares; pure host
+logic reachable without a GPU behaves.  No compute calls here."""
+import ctypes
+import os
+
+import pytest
+
+from reef_amd import _ffi, msm
+
+
+def test_library_present_and_loads():
+    assert os.path.exists(_ffi.LIB_PATH), "run __graft_entry__.build() first"
+    lib = _ffi.load()
+    assert lib.reef_version().startswith(b"reef_msm")
+
+
+def test_exports_every_declared_symbol():
+    names = _ffi.declared_symbols()
+    assert "mult_pippenger_pallas" in names and "reef_msm_rows" in names and len(names) >= 25
+    raw = ctypes.CDLL(_ffi.LIB_PATH)
+    missing = [n for n in names if not hasattr(raw, n)]
+    assert not missing, missing
+
+
+def test_struct_sizes_match_header():
+    assert ctypes.sizeof(_ffi.MsmOpts) == 32
+
+
+def test_plan_for_host_logic():
+    # pure host planning logic: W = ceil(256/c), T = ceil(W/G)
+    p = msm.plan_for(1 << 20)
+    assert p["windows"] == -(-256 // p["window_bits"]) and p["bucket_groups"] == p["windows"] and p["tables"] == 1
+    assert 12 <= p["window_bits"] <= 18
+    p = msm.plan_for(1 << 20, bucket_groups=1)
+    assert p["bucket_groups"] == 1 and p["tables"] == p["windows"]
+    p = msm.plan_for(1 << 16, window_bits=13, bucket_groups=4)
+    assert p == {"window_bits": 13, "windows": 20, "bucket_groups": 4, "tables": 5}
+    small, big = msm.plan_for(200)["window_bits"], msm.plan_for(1 << 22)["window_bits"]
+    assert small < big
+    with pytest.raises(msm.ReefError):
+        msm.plan_for(100, window_bits=25)
+
+
+def test_unknown_curve_rejected():
+    with pytest.raises(ValueError):
+        msm.curve_id("bls12")
+
+
+def test_fails_loudly_without_gpu():
+    lib = _ffi.load()
+    if lib.reef_device_count() > 0:
+        pytest.skip("a GPU is present")
+    import numpy as np
+    with pytest.raises(msm.ReefError) as e:
+        msm.MsmContext("pallas", np.zeros((4, 8), dtype=np.uint64))
+    assert e.value.status == 3  # REEF_ERR_NO_GPU: no silent CPU fallback

@@ -1,0 +1,319 @@
+"""Parity of the HIP path (through the C ABI) against the oracle and the golden vectors.
+
+Bit-exact on the canonical encodings (affine Montgomery limbs / 32-byte compressed points):
+Jacobian representatives are not unique, so outputs are normalised before comparison.
+"""
+import hashlib
+import threading
+
+import numpy as np
+import pytest
+
+from oracle.pasta_oracle import CURVES, SplitMix64, msm_via_dlog, uniform_scalar
+
+pytestmark = pytest.mark.gpu
+CID = {"pallas": 0, "vesta": 1}
+
+
+def limbs(v):
+    return [(v >> (64 * i)) & 0xFFFFFFFFFFFFFFFF for i in range(4)]
+
+
+def explicit_arrays(case):
+    n = len(case["bases_hex"])
+    if n == 0:
+        return np.zeros((0, 8), np.uint64), np.zeros((0, 4), np.uint64), np.zeros((0, 4), np.uint64)
+    bases = np.frombuffer(b"".join(bytes.fromhex(h) for h in case["bases_hex"]), dtype=np.uint64).reshape(n, 8).copy()
+    sm = np.frombuffer(b"".join(bytes.fromhex(h) for h in case["scalars_mont_hex"]), dtype=np.uint64).reshape(n, 4).copy()
+    sc = np.frombuffer(b"".join(bytes.fromhex(h) for h in case["scalars_canon_hex"]), dtype=np.uint64).reshape(n, 4).copy()
+    return bases, sm, sc
+
+
+# ------------------------------------------------------------------ field / group law ----
+@pytest.mark.parametrize("name", ["pallas", "vesta"])
+def test_field_ops(name, gpu_lib, cref):
+    f = CID[name]
+    m = CURVES[name].base
+    rng = SplitMix64(1234 + f)
+    vals = [0, 1, 2, m - 1, m - 2, (1 << 255) % m, (1 << 254), (1 << 128) - 1, 0xFFFFFFFF, 1 << 32]
+    vals += [uniform_scalar(rng, m) for _ in range(246)]
+    n = len(vals)
+    a = np.array([limbs(v) for v in vals], dtype=np.uint64)
+    b = np.array([limbs(v) for v in reversed(vals)], dtype=np.uint64)
+    out = np.zeros_like(a)
+    for op, name_c, unary in ((0, "fmul", False), (1, "fadd", False), (2, "fsub", False), (3, "finv", True),
+                              (4, "to_mont", True), (5, "from_mont", True)):
+        assert gpu_lib.reef_test_field_op(f, op, a.ctypes.data, b.ctypes.data, out.ctypes.data, n) == 0
+        for i in range(n):
+            exp = cref.field_op(name_c, f, a[i].copy()) if unary else cref.field_op(name_c, f, a[i].copy(), b[i].copy())
+            assert (out[i] == exp).all(), (name_c, i, hex(vals[i]))
+    # neg and sqr against big ints
+    assert gpu_lib.reef_test_field_op(f, 6, a.ctypes.data, b.ctypes.data, out.ctypes.data, n) == 0
+    for i in range(n):
+        assert cref.limbs_to_int(out[i]) == (-vals[i]) % m
+    assert gpu_lib.reef_test_field_op(f, 7, a.ctypes.data, b.ctypes.data, out.ctypes.data, n) == 0
+    rinv = pow(1 << 256, -1, m)
+    for i in range(n):
+        assert cref.limbs_to_int(out[i]) == vals[i] * vals[i] * rinv % m
+
+
+@pytest.mark.parametrize("name", ["pallas", "vesta"])
+def test_group_law(name, gpu_lib, cref):
+    from reef_amd import msm
+    cid = CID[name]
+    C = CURVES[name]
+    n = 64
+    P = cref.gen_bases_ap(cid, 3, 5, n)
+    Qp = cref.gen_bases_ap(cid, 1000, 9, n)
+    # special cases: P == Q (doubling), P == -Q, identity operands
+    Qp[0] = P[0]
+    Qp[1] = np.frombuffer(C.affine_to_bytes(C.neg(C.affine_from_bytes(P[1].tobytes()))), dtype=np.uint64)
+    Qp[2] = 0
+    P[3] = 0
+    P[4] = 0
+    Qp[4] = 0
+    rng = SplitMix64(5)
+    ks = [uniform_scalar(rng, C.order) for _ in range(n)]
+    ks[0], ks[1], ks[2] = 0, 1, C.order - 1
+    k = np.array([limbs(v) for v in ks], dtype=np.uint64)
+    out = np.zeros((n, 12), dtype=np.uint64)
+    pts = [C.affine_from_bytes(P[i].tobytes()) for i in range(n)]
+    qts = [C.affine_from_bytes(Qp[i].tobytes()) for i in range(n)]
+    for op in (0, 1, 2, 3):
+        assert gpu_lib.reef_test_ec_op(cid, op, P.ctypes.data, Qp.ctypes.data, k.ctypes.data, out.ctypes.data, n) == 0
+        comp = cref.compress(cid, out)
+        gcomp = msm.compress(cid, out)
+        assert comp == gcomp  # K4 normalise/compress on the GPU == oracle
+        for i in range(n):
+            exp = {0: lambda: C.add(pts[i], qts[i]), 1: lambda: C.add(pts[i], qts[i]), 2: lambda: C.add(pts[i], pts[i]),
+                   3: lambda: C.mul(ks[i], pts[i])}[op]()
+            assert comp[32 * i:32 * i + 32] == C.compress(exp), (op, i)
+
+
+# ---------------------------------------------------------------------------- K1: MSM ----
+def test_golden_explicit_stateless(golden, gpu_lib):
+    """pasta-msm drop-in symbols, both scalar conventions (is_mont true / false)."""
+    from reef_amd import msm
+    for case in golden["explicit"]:
+        bases, sm, sc = explicit_arrays(case)
+        for scal, mont in ((sm, True), (sc, False)):
+            r = msm.mult_pippenger(case["curve"], bases, scal, is_mont=mont)
+            assert msm.compress(case["curve"], r).hex() == case["expect_compressed"], (case["label"], mont)
+
+
+@pytest.mark.parametrize("groups", [0, 1, 4])
+def test_golden_explicit_handle(golden, gpu_lib, groups):
+    from reef_amd import msm
+    for case in golden["explicit"]:
+        bases, sm, sc = explicit_arrays(case)
+        if bases.shape[0] == 0:
+            continue
+        with msm.MsmContext(case["curve"], bases, window_bits=5, bucket_groups=groups) as ctx:
+            r = ctx.msm(sm)
+            assert msm.compress(case["curve"], r).hex() == case["expect_compressed"], (case["label"], groups)
+            r = ctx.msm(sc, is_mont=False)
+            assert msm.compress(case["curve"], r).hex() == case["expect_compressed"], (case["label"], groups)
+
+
+def test_golden_seeded(golden, gpu_lib):
+    """Sizes {1,2,3,127,128,129,1000,4096}, uniform and witness-like scalars; inputs generated on
+    the GPU must be byte-identical to the oracle's (sha256 pinned in the fixture)."""
+    from reef_amd import msm
+    for case in golden["seeded"]:
+        n = case["n"]
+        bases = msm.gen_bases(case["curve"], case["k0"], case["d"], n)
+        sc = msm.gen_scalars(case["curve"], case["seed"], n, kind=case["kind"])
+        assert hashlib.sha256(bases.tobytes() + sc.tobytes()).hexdigest() == case["input_sha256"], (case["curve"], n)
+        r = msm.mult_pippenger(case["curve"], bases, sc)
+        assert msm.compress(case["curve"], r).hex() == case["expect_compressed"], (case["curve"], n, case["kind"])
+
+
+@pytest.mark.parametrize("name", ["pallas", "vesta"])
+@pytest.mark.parametrize("plan", [(0, 0), (7, 0), (7, 1), (9, 3), (12, 1), (13, 0), (16, 0), (4, 2)])
+def test_plans_vs_c_oracle(name, plan, gpu_lib, cref):
+    """Every (window, bucket-group) plan gives the oracle's answer; prefix MSMs (n < key length)."""
+    from reef_amd import msm
+    cid = CID[name]
+    n = 3000
+    bases = cref.gen_bases_ap(cid, 17, 3, n)
+    with msm.MsmContext(cid, bases, window_bits=plan[0], bucket_groups=plan[1]) as ctx:
+        for kind, m in ((0, n), (1, n), (0, 777), (2, 1500)):
+            sc = cref.gen_scalars(cid, 99 + kind + m, m, kind=kind, small_bound=131)
+            exp = cref.compress(cid, cref.msm_pippenger(cid, bases[:m].copy(), sc, threads=4))
+            got = msm.compress(cid, ctx.msm(sc))
+            assert got == exp, (plan, kind, m)
+
+
+@pytest.mark.parametrize("name", ["pallas", "vesta"])
+def test_skewed_and_degenerate_inputs(name, gpu_lib, cref):
+    """Heavy buckets (all scalars equal), duplicate bases (P+P inside a bucket), cancelling pairs."""
+    from reef_amd import msm
+    cid = CID[name]
+    C = CURVES[name]
+    n = 5000
+    bases = cref.gen_bases_ap(cid, 5, 1, n)
+    with msm.MsmContext(cid, bases) as ctx:
+        for val in (1, 2, C.order - 1, 0x8000, 0xFFFF):
+            sc = np.tile(np.array(limbs(val), dtype=np.uint64), (n, 1))
+            exp = cref.compress(cid, cref.msm_pippenger(cid, bases, sc, mont=False, threads=4))
+            assert msm.compress(cid, ctx.msm(sc, is_mont=False)) == exp, hex(val)
+    dup = np.tile(bases[7], (n, 1))
+    dup[1::2] = np.frombuffer(C.affine_to_bytes(C.neg(C.affine_from_bytes(bases[7].tobytes()))), dtype=np.uint64)
+    with msm.MsmContext(cid, dup) as ctx:
+        sc = np.tile(np.array(limbs(3), dtype=np.uint64), (n, 1))
+        assert msm.compress(cid, ctx.msm(sc, is_mont=False)) == bytes(32)  # everything cancels
+        sc = cref.gen_scalars(cid, 1, n, kind=0)
+        exp = cref.compress(cid, cref.msm_pippenger(cid, dup, sc, threads=4))
+        assert msm.compress(cid, ctx.msm(sc)) == exp
+    same = np.tile(bases[9], (64, 1))
+    with msm.MsmContext(cid, same) as ctx:
+        sc = np.tile(np.array(limbs(5), dtype=np.uint64), (64, 1))
+        pt = C.mul(5 * 64, C.affine_from_bytes(bases[9].tobytes()))
+        assert msm.compress(cid, ctx.msm(sc, is_mont=False)) == C.compress(pt)
+
+
+@pytest.mark.parametrize("name,logn,kind,groups", [("pallas", 20, 0, 0), ("pallas", 20, 1, 0), ("vesta", 18, 0, 0),
+                                                   ("pallas", 18, 0, 1), ("vesta", 17, 1, 1)])
+def test_full_size_dlog_property(name, logn, kind, groups, gpu_lib):
+    """BASELINE.json configs[1] size (2^20 Pallas): device-generated bases in arithmetic
+    progression, so the result must equal (sum_i s_i*(k0 + i*d)) * G -- a size-independent check
+    that needs only O(n) big-int work on the host."""
+    from reef_amd import msm
+    C = CURVES[name]
+    n = 1 << logn
+    k0, d = 0xABCDEF, 0x12345
+    bases = msm.gen_bases(name, k0, d, n, device=True)
+    sc_dev = msm.gen_scalars(name, 0x5EEF, n, kind=kind, mont=True, device=True)
+    sc = sc_dev.to_host((n, 4))
+    canon = msm.gen_scalars(name, 0x5EEF, n, kind=kind, mont=False)
+    with msm.MsmContext(name, bases, n, bucket_groups=groups) as ctx:
+        r_dev = ctx.msm(sc_dev, n)            # device-resident scalars
+        r_host = ctx.msm(sc)                  # host scalars through the same key
+        ctx.sync()
+    cols = [canon[:, j].astype(object) for j in range(4)]
+    idx = np.arange(n, dtype=object)
+    acc = 0
+    for j in range(4):
+        acc += (int(np.sum(cols[j])) * k0 + int(np.sum(cols[j] * idx)) * d) << (64 * j)
+    exp = C.compress(C.mul(acc % C.order, C.gen))
+    assert msm.compress(name, r_host) == exp
+    assert msm.compress(name, r_dev) == exp
+    # Montgomery-form input really is the Montgomery image of the canonical one
+    assert C.scalar_from_mont(int.from_bytes(sc[12345].tobytes(), "little")) == int.from_bytes(canon[12345].tobytes(), "little")
+
+
+def test_linearity_and_clone_threads(gpu_lib, cref):
+    """MSM(a) + MSM(b) == MSM(a+b); clones of one key used from several threads agree."""
+    from reef_amd import msm
+    cid = 0
+    C = CURVES["pallas"]
+    n = 20000
+    bases = cref.gen_bases_ap(cid, 123, 11, n)
+    a = cref.gen_scalars(cid, 10, n, mont=False)
+    b = cref.gen_scalars(cid, 11, n, mont=False)
+    s = np.zeros_like(a)
+    for i in range(n):
+        v = (cref.limbs_to_int(a[i]) + cref.limbs_to_int(b[i])) % C.order
+        s[i] = limbs(v)
+    with msm.MsmContext(cid, bases, bucket_groups=2) as ctx:
+        ra, rb, rs = ctx.msm(a, is_mont=False), ctx.msm(b, is_mont=False), ctx.msm(s, is_mont=False)
+        total = msm.sum_points(cid, np.stack([ra, rb]))
+        assert msm.compress(cid, total) == msm.compress(cid, rs)
+        clones = [ctx.clone() for _ in range(3)]
+        results = [None] * 3
+
+        def work(j):
+            for _ in range(3):
+                results[j] = msm.compress(cid, clones[j].msm(s, is_mont=False))
+        ts = [threading.Thread(target=work, args=(j,)) for j in range(3)]
+        [t.start() for t in ts]
+        [t.join() for t in ts]
+        assert all(r == msm.compress(cid, rs) for r in results)
+        for c in clones:
+            c.close()
+
+
+def test_error_paths(gpu_lib, cref):
+    from reef_amd import msm
+    bases = cref.gen_bases_ap(0, 1, 1, 16)
+    with msm.MsmContext(0, bases) as ctx:
+        with pytest.raises(ValueError):
+            ctx.msm(np.zeros((17, 4), dtype=np.uint64))      # longer than the key: the reference panics
+        assert (ctx.msm(np.zeros((0, 4), dtype=np.uint64)) == 0).all()  # empty MSM = identity (0,0,0)
+    with pytest.raises(msm.ReefError):
+        msm.MsmContext(0, bases, window_bits=31)
+    with pytest.raises(ValueError):
+        msm.mult_pippenger(0, bases, np.zeros((3, 4), dtype=np.uint64))
+
+
+# ------------------------------------------------------------------ K2 rows / K3 / K4 ----
+def test_rows_golden(golden, gpu_lib, cref):
+    from reef_amd import msm
+    for case in golden["rows"]:
+        C = CURVES[case["curve"]]
+        cid = CID[case["curve"]]
+        rows, row_len = case["rows"], case["row_len"]
+        bases = cref.gen_bases_ap(cid, case["k0"], case["d"], row_len)
+        sc = np.array([[s, 0, 0, 0] for s in case["scalars"]], dtype=np.uint64)
+        bl = np.array([limbs(int(b, 16)) for b in case["blinds"]], dtype=np.uint64)
+        h = np.frombuffer(C.affine_to_bytes(C.mul(case["h_k"], C.gen)), dtype=np.uint64).copy()
+        with msm.MsmContext(cid, bases) as ctx:
+            for bits in (0, 3, 8):
+                out = ctx.msm_rows(sc, rows, row_len, is_mont=False, max_scalar_bits=bits, blinds=bl, h=h)
+                comp = msm.compress(cid, out)
+                assert [comp[32 * i:32 * i + 32].hex() for i in range(rows)] == case["expect_compressed"], bits
+
+
+@pytest.mark.parametrize("name,rows,row_len,bound", [("pallas", 64, 512, 7), ("pallas", 32, 2048, 131), ("vesta", 16, 300, 131),
+                                                      ("pallas", 8, 1000, 0), ("pallas", 1, 700, 7)])
+def test_rows_vs_c_oracle(name, rows, row_len, bound, gpu_lib, cref):
+    """Hyrax-shaped commits (commitment.rs:187): DNA-like (<7), ASCII-like (<131) and full-width rows."""
+    from reef_amd import msm
+    cid = CID[name]
+    bases = cref.gen_bases_ap(cid, 77, 13, row_len)
+    kind = 2 if bound else 0
+    sc = cref.gen_scalars(cid, 31337, rows * row_len, kind=kind, small_bound=bound)
+    bl = cref.gen_scalars(cid, 4, rows)
+    h = cref.gen_bases_ap(cid, 0xB11D, 1, 1)[0].copy()
+    exp = cref.compress(cid, cref.row_msm(cid, bases, sc, rows, row_len, h=h, blinds=bl, threads=4))
+    with msm.MsmContext(cid, bases) as ctx:
+        out = ctx.msm_rows(sc, rows, row_len, blinds=bl, h=h)
+        assert msm.compress(cid, out) == exp
+        exp_nb = cref.compress(cid, cref.row_msm(cid, bases, sc, rows, row_len, threads=4))
+        assert msm.compress(cid, ctx.msm_rows(sc, rows, row_len)) == exp_nb
+
+
+def test_fold_golden_and_oracle(golden, gpu_lib, cref):
+    from reef_amd import msm
+    for case in golden["fold"]:
+        cid = CID[case["curve"]]
+        gens = cref.gen_bases_ap(cid, case["k0"], case["d"], case["n"])
+        out = msm.fold(cid, gens, case["n"] // 2, int(case["w1"], 16), int(case["w2"], 16))
+        jac = np.zeros((out.shape[0], 12), dtype=np.uint64)
+        jac[:, :8] = out
+        jac[:, 8:] = cref.field_op("to_mont", cid, cref.int_to_limbs(1))
+        comp = cref.compress(cid, jac)
+        assert [comp[32 * i:32 * i + 32].hex() for i in range(out.shape[0])] == case["expect_compressed"]
+    for cid, name in ((0, "pallas"), (1, "vesta")):
+        C = CURVES[name]
+        rng = SplitMix64(808)
+        gens = cref.gen_bases_ap(cid, 9, 4, 1000)
+        gens[3] = gens[503]            # L_i == R_i
+        gens[5] = 0                    # identity generator
+        w1, w2 = uniform_scalar(rng, C.order), uniform_scalar(rng, C.order)
+        assert (msm.fold(cid, gens, 500, w1, w2) == cref.fold(cid, gens, w1, w2)).all()
+        assert (msm.fold(cid, gens, 500, w1, w1) == cref.fold(cid, gens, w1, w1)).all()
+
+
+def test_normalize_matches_oracle(gpu_lib, cref):
+    from reef_amd import msm
+    for cid in (0, 1):
+        n = 1003
+        bases = cref.gen_bases_ap(cid, 2, 3, n)
+        jac = np.zeros((n, 12), dtype=np.uint64)
+        for i in range(n):
+            jac[i] = cref.scalar_mul(cid, bases[i], 3 + i)   # Z != 1
+        jac[10] = 0                                          # identity (0,0,0)
+        aff, comp = msm.normalize(cid, jac, affine=True, compressed=True)
+        assert (aff == cref.to_affine(cid, jac)).all()
+        assert comp.tobytes() == cref.compress(cid, jac)
