@@ -151,6 +151,14 @@ const char *reef_version(void);
 /* Timing of the last reef_msm / reef_msm_rows on this ctx, measured with HIP events on the ctx's
  * stream (valid after a sync): total and the accumulation kernel alone, in milliseconds. */
 reef_status reef_msm_ctx_last_timing(reef_msm_ctx *ctx, float *total_ms, float *accumulate_ms);
+/* The same, summed over every MSM issued on this ctx since the last reset: number of calls, total
+ * milliseconds and milliseconds inside the bucket-accumulation kernel (HIP events recorded on the
+ * ctx's stream around each launch; the call waits for MSMs still in flight). */
+reef_status reef_msm_ctx_timing_stats(reef_msm_ctx *ctx, int reset, uint64_t *calls, double *total_ms,
+                                      double *accumulate_ms);
+/* Sum of n Jacobian points, enqueued on the ctx's stream (device buffers only): combines the
+ * per-rank partial MSMs after an RCCL all-gather ordered on the same stream. */
+reef_status reef_msm_ctx_sum_points(reef_msm_ctx *ctx, const reef_jacobian *in, size_t n, reef_jacobian *out);
 /* Plan actually used by the ctx: window bits, windows, bucket groups, tables. */
 reef_status reef_msm_ctx_plan(reef_msm_ctx *ctx, uint32_t *c, uint32_t *windows, uint32_t *groups,
                               uint32_t *tables);

@@ -129,6 +129,14 @@ reef_status reef_msm_ctx_last_timing(reef_msm_ctx *ctx, float *total_ms, float *
     if (!ctx) { set_error("null argument"); return REEF_ERR_ARG; }
     return vt(ctx->curve)->ctx_timing(ctx->impl, total_ms, accumulate_ms);
 }
+reef_status reef_msm_ctx_timing_stats(reef_msm_ctx *ctx, int reset, uint64_t *calls, double *total_ms, double *accumulate_ms) {
+    if (!ctx) { set_error("null argument"); return REEF_ERR_ARG; }
+    return vt(ctx->curve)->ctx_timing_stats(ctx->impl, reset, calls, total_ms, accumulate_ms);
+}
+reef_status reef_msm_ctx_sum_points(reef_msm_ctx *ctx, const reef_jacobian *in, size_t n, reef_jacobian *out) {
+    if (!ctx) { set_error("null argument"); return REEF_ERR_ARG; }
+    return vt(ctx->curve)->ctx_sum_points(ctx->impl, in, n, out);
+}
 reef_status reef_msm_ctx_plan(reef_msm_ctx *ctx, uint32_t *c, uint32_t *windows, uint32_t *groups, uint32_t *tables) {
     if (!ctx) { set_error("null argument"); return REEF_ERR_ARG; }
     return vt(ctx->curve)->ctx_plan(ctx->impl, c, windows, groups, tables);

@@ -62,6 +62,54 @@ __global__ void __launch_bounds__(256) p_mad_mix(uint32_t *out, uint32_t seed) {
     out[TID] = (uint32_t)(a0 ^ a1) ^ b0 ^ b1;
 }
 
+U32_PROBE(p_bfi, 3u, "v_bfi_b32 %0, %4, %0, %1\n v_bfi_b32 %1, %4, %1, %2\n v_bfi_b32 %2, %4, %2, %3\n v_bfi_b32 %3, %4, %3, %0")
+U32_PROBE(p_xor, 3u, "v_xor_b32 %0, %0, %4\n v_xor_b32 %1, %1, %4\n v_xor_b32 %2, %2, %4\n v_xor_b32 %3, %3, %4")
+U32_PROBE(p_and_or, 3u, "v_and_or_b32 %0, %0, %4, %1\n v_and_or_b32 %1, %1, %4, %2\n v_and_or_b32 %2, %2, %4, %3\n v_and_or_b32 %3, %3, %4, %0")
+U32_PROBE(p_add3, 3u, "v_add3_u32 %0, %0, %4, %1\n v_add3_u32 %1, %1, %4, %2\n v_add3_u32 %2, %2, %4, %3\n v_add3_u32 %3, %3, %4, %0")
+U32_PROBE(p_subb, 0xf0000003u, "v_sub_co_u32 %0, vcc, %0, %4\n v_subb_co_u32 %1, vcc, %1, %4, vcc\n v_subb_co_u32 %2, vcc, %2, %4, vcc\n v_subb_co_u32 %3, vcc, %3, %4, vcc")
+U32_PROBE(p_cmp_cnd, 3u, "v_cmp_gt_u32 vcc, %0, %4\n v_cndmask_b32 %1, %1, %4, vcc\n v_cmp_gt_u32 vcc, %2, %4\n v_cndmask_b32 %3, %3, %4, vcc")
+U32_PROBE(p_alignbit, 3u, "v_alignbit_b32 %0, %0, %1, 29\n v_alignbit_b32 %1, %1, %2, 29\n v_alignbit_b32 %2, %2, %3, 29\n v_alignbit_b32 %3, %3, %0, 29")
+U32_PROBE(p_lshr, 3u, "v_lshrrev_b32 %0, 3, %0\n v_lshrrev_b32 %1, 3, %1\n v_lshrrev_b32 %2, 3, %2\n v_lshrrev_b32 %3, 3, %3")
+U32_PROBE(p_mov, 3u, "v_mov_b32 %0, %1\n v_mov_b32 %1, %2\n v_mov_b32 %2, %3\n v_mov_b32 %3, %4")
+
+__global__ void __launch_bounds__(256) p_cnd_sgpr(uint32_t *out, uint32_t seed) {
+    uint32_t a0 = seed + threadIdx.x, a1 = a0 + 1, a2 = a0 + 2, a3 = a0 + 3;
+    uint32_t y = threadIdx.x | 3;
+    uint64_t m = 0x5555aaaa5555aaaaull ^ seed;
+    LOOP(asm volatile("v_cndmask_b32_e64 %0, %0, %4, %5\n v_cndmask_b32_e64 %1, %1, %4, %5\n v_cndmask_b32_e64 %2, %2, %4, %5\n v_cndmask_b32_e64 %3, %3, %4, %5"
+                      : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(y), "s"(m)));
+    out[TID] = a0 ^ a1 ^ a2 ^ a3;
+}
+__global__ void __launch_bounds__(256) p_lshl_add64(uint32_t *out, uint32_t seed) {
+    uint64_t a0 = seed + threadIdx.x, a1 = a0 + 1, a2 = a0 + 2, a3 = a0 + 3;
+    uint64_t y = ((uint64_t)threadIdx.x << 33) | 3;
+    LOOP(asm volatile("v_lshl_add_u64 %0, %0, 0, %4\n v_lshl_add_u64 %1, %1, 0, %4\n v_lshl_add_u64 %2, %2, 0, %4\n v_lshl_add_u64 %3, %3, 0, %4"
+                      : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(y)));
+    out[TID] = (uint32_t)(a0 ^ a1 ^ a2 ^ a3);
+}
+__global__ void __launch_bounds__(256) p_lshr64(uint32_t *out, uint32_t seed) {
+    uint64_t a0 = seed + threadIdx.x, a1 = a0 + 1, a2 = a0 + 2, a3 = a0 + 3;
+    LOOP(asm volatile("v_lshrrev_b64 %0, 1, %0\n v_lshrrev_b64 %1, 1, %1\n v_lshrrev_b64 %2, 1, %2\n v_lshrrev_b64 %3, 1, %3"
+                      : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3)));
+    out[TID] = (uint32_t)(a0 ^ a1 ^ a2 ^ a3);
+}
+// mad with carry-out to an SGPR pair consumed by v_addc (the even/odd accumulation shape)
+__global__ void __launch_bounds__(256) p_mad_addc(uint32_t *out, uint32_t seed) {
+    uint64_t a0 = seed + threadIdx.x, a1 = a0 + 1;
+    uint32_t k0 = 0, k1 = 0, x = seed | 0x80000001u, y = threadIdx.x | 0xc0000003u;
+    LOOP(asm volatile("v_mad_u64_u32 %0, vcc, %4, %5, %0\n v_addc_co_u32 %2, vcc, 0, %2, vcc\n"
+                      "v_mad_u64_u32 %1, vcc, %4, %5, %1\n v_addc_co_u32 %3, vcc, 0, %3, vcc"
+                      : "+v"(a0), "+v"(a1), "+v"(k0), "+v"(k1) : "v"(x), "v"(y) : "vcc"));
+    out[TID] = (uint32_t)(a0 ^ a1) ^ k0 ^ k1;
+}
+__global__ void __launch_bounds__(256) p_bpermute(uint32_t *out, uint32_t seed) {
+    uint32_t a0 = seed + threadIdx.x, a1 = a0 + 1, a2 = a0 + 2, a3 = a0 + 3;
+    uint32_t idx = ((threadIdx.x + 5) & 63) * 4;
+    LOOP(asm volatile("ds_bpermute_b32 %0, %4, %0\n ds_bpermute_b32 %1, %4, %1\n ds_bpermute_b32 %2, %4, %2\n ds_bpermute_b32 %3, %4, %3\n s_waitcnt lgkmcnt(0)"
+                      : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(idx)));
+    out[TID] = a0 ^ a1 ^ a2 ^ a3;
+}
+
 typedef void (*probe_fn)(uint32_t *, uint32_t);
 
 static double run_probe(const char *name, probe_fn fn, int insts_per_iter, int blocks_per_cu, uint32_t *out) {
@@ -135,7 +183,7 @@ int main() {
     printf("device: %s  CUs=%d  clock=%d MHz\n", prop.gcnArchName, prop.multiProcessorCount, prop.clockRate / 1000);
     uint32_t *out;
     CHECK(hipMalloc(&out, 256 * 16 * 256 * sizeof(uint32_t)));
-    for (int bpc : {4, 8}) {
+    for (int bpc : {2, 8}) {
         run_probe("v_mad_u64_u32", p_mad64, UNROLL, bpc, out);
         run_probe("v_mul_lo_u32", p_mul_lo, UNROLL, bpc, out);
         run_probe("v_mul_hi_u32", p_mul_hi, UNROLL, bpc, out);
@@ -147,6 +195,20 @@ int main() {
         run_probe("v_fma_f64", p_fma_f64, UNROLL, bpc, out);
         run_probe("v_fma_f32", p_fma_f32, UNROLL, bpc, out);
         run_probe("mad+2adds x2", p_mad_mix, 6 * (UNROLL / 4), bpc, out);
+        run_probe("mad+addc x2", p_mad_addc, 4 * (UNROLL / 4), bpc, out);
+        run_probe("v_bfi_b32", p_bfi, UNROLL, bpc, out);
+        run_probe("v_xor_b32", p_xor, UNROLL, bpc, out);
+        run_probe("v_and_or_b32", p_and_or, UNROLL, bpc, out);
+        run_probe("v_add3_u32", p_add3, UNROLL, bpc, out);
+        run_probe("v_subb chain", p_subb, UNROLL, bpc, out);
+        run_probe("cmp+cndmask", p_cmp_cnd, UNROLL, bpc, out);
+        run_probe("cndmask sgpr", p_cnd_sgpr, UNROLL, bpc, out);
+        run_probe("v_alignbit", p_alignbit, UNROLL, bpc, out);
+        run_probe("v_lshrrev_b32", p_lshr, UNROLL, bpc, out);
+        run_probe("v_mov_b32", p_mov, UNROLL, bpc, out);
+        run_probe("v_lshl_add_u64", p_lshl_add64, UNROLL, bpc, out);
+        run_probe("v_lshrrev_b64", p_lshr64, UNROLL, bpc, out);
+        run_probe("ds_bpermute", p_bpermute, UNROLL, bpc, out);
     }
     // LDS atomics: 1024-thread blocks, 32768 counters (128 KiB)
     CHECK(hipFuncSetAttribute((const void *)p_lds_atomic, hipFuncAttributeMaxDynamicSharedMemorySize, 131072));

@@ -146,6 +146,21 @@ class MsmContext:
         check(self._lib.reef_msm_ctx_last_timing(self._h, ctypes.byref(a), ctypes.byref(b)))
         return a.value, b.value
 
+    def timing_stats(self, reset: bool = True) -> dict:
+        """Sums over the MSMs issued since the last reset (waits for those still in flight)."""
+        calls, tot, acc = ctypes.c_uint64(), ctypes.c_double(), ctypes.c_double()
+        check(self._lib.reef_msm_ctx_timing_stats(self._h, int(reset), ctypes.byref(calls), ctypes.byref(tot), ctypes.byref(acc)))
+        return {"calls": calls.value, "total_ms": tot.value, "accumulate_ms": acc.value}
+
+    def sum_points(self, jac: Buf, n: int, out: Buf) -> Buf:
+        """Sum n device-resident Jacobian points on this context's stream."""
+        loc, ptr = _loc_ptr(jac, 96 * n)
+        oloc, optr = _loc_ptr(out, 96)
+        if loc != REEF_DEVICE or oloc != REEF_DEVICE:
+            raise ValueError("device buffers only")
+        check(self._lib.reef_msm_ctx_sum_points(self._h, ptr, n, optr))
+        return out
+
     def msm(self, scalars: Buf, n: Optional[int] = None, *, is_mont: bool = True, out: Optional[Buf] = None) -> Buf:
         """sum_i scalars[i]*bases[i].  Host result: uint64[12] Jacobian.  With a device `out`
         the call only enqueues work on the context's stream."""
