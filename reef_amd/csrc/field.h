@@ -1,13 +1,26 @@
 // Pasta base/scalar field arithmetic for gfx950 (and, for CPU-side unit tests only, the host).
 //
-// Fp / Fq of fil_pasta_curves 0.5.2 (Cargo.toml:14 of the reference): 255-bit primes,
-// Montgomery form with R = 2^256, stored as 4 x u64 little-endian == 8 x u32 little-endian.
-// On the GPU a field element lives in 8 VGPRs; products are formed with v_mad_u64_u32
-// (32x32+64 -> 64).  Both moduli have the shape
-//      M = 2^254 + (m3:m2:m1:1)        (limbs 4,5,6 = 0, limb 7 = 0x40000000, limb 0 = 1)
-// and -M^-1 mod 2^32 = 0xffffffff, so a CIOS reduction round needs only 3 real
-// multiplications (by m1, m2, m3), a shift (the 2^254 term) and no multiplication for
-// the quotient digit (q = -t0).  88 MADs per Montgomery product instead of 128.
+// Fp / Fq of fil_pasta_curves 0.5.2 (Cargo.toml:14 of the reference) are 255-bit primes.  At
+// the C ABI an element is 4 x u64 little-endian limbs in Montgomery form with R = 2^256.
+//
+// Inside the kernels an element is NINE 29-bit limbs in 32-bit registers ("unsaturated"):
+// measured on MI355X (profiles/r01_ubench_instruction_rates.txt) v_mad_u64_u32 issues at the
+// same rate as any other 3-operand VALU instruction, so the cost of a Montgomery product is
+// its instruction count, and 32-bit limbs pay one extra carry instruction per partial
+// product.  With 29-bit limbs a 64-bit column accumulator absorbs all 15 partial products of
+// a column without a single carry: a product is 81 + 54 MADs and ~60 cheap instructions.
+// The internal Montgomery radix is R' = 2^261 (9 x 29); keys are converted once at upload,
+// results once at output (field_consts.h: C_IN, C_OUT).  Both moduli are
+//      M = 2^254 + delta,  delta < 2^126   =>  limbs (1, M1, M2, M3, M4, 0, 0, 0, 2^22)
+// and M = 1 mod 2^29, so the Montgomery quotient digit is q = -t0 mod 2^29 and a reduction
+// round costs 6 MADs.
+//
+// Value bounds.  Limbs are "normalised" when l0..l7 <= 2^29 + 7 (l0 < 2^29 exactly) and the
+// top limb holds the rest.  A product needs (A/M)*(B/M) < 128 and returns a value < 2M with
+// exact 29-bit limbs; a - b is computed as a + k*M - b with a bias k*M whose limbs are all
+// >= 2^31 - 4 (field_consts.h: BIASk), valid for b < k*M.  The bound of every intermediate
+// in the group law is stated next to it in ec.h and machine-checked on the host by
+// tests/test_host_math.py (REEF_BOUNDS build).
 #pragma once
 #include <stdint.h>
 
@@ -19,200 +32,366 @@
 #endif
 
 namespace reef {
-
 typedef uint32_t u32;
 typedef uint64_t u64;
+typedef int64_t i64;
+}  // namespace reef
 
-struct alignas(16) fe {
-    u32 v[8];
+#include "field_consts.h"
+
+#if defined(REEF_BOUNDS)
+#include <assert.h>
+#include <stdio.h>
+#include <stdlib.h>
+#define REEF_BOUND_FAIL(msg) do { fprintf(stderr, "REEF_BOUNDS violation: %s (%s:%d)\n", msg, __FILE__, __LINE__); abort(); } while (0)
+#endif
+
+namespace reef {
+
+static constexpr u32 LIMB_BITS = 29;
+static constexpr u32 LIMB_MASK = (1u << LIMB_BITS) - 1u;
+
+// 9 x 29-bit limbs, Montgomery form w.r.t. R' = 2^261.
+struct fe {
+    u32 l[9];
+#if defined(REEF_BOUNDS)
+    double bound;  // value < bound * M  (host-side bound tracking only)
+#endif
 };
 
-// F = 0: Fp (Pallas coordinates, Vesta scalars); F = 1: Fq (Vesta coordinates, Pallas scalars).
-// q is the CirC modulus Reef hard-codes at src/backend/r1cs_helper.rs:37-38.
-template <int F> struct Mod;
-template <> struct Mod<0> {
-    static constexpr u32 M1 = 0x992d30edu, M2 = 0x094cf91bu, M3 = 0x224698fcu;
-    // R mod p, R^2 mod p (verified with big ints)
-    static constexpr u32 R1[8] = {0xfffffffdu, 0x34786d38u, 0xe41914adu, 0x992c350bu,
-                                  0xffffffffu, 0xffffffffu, 0xffffffffu, 0x3fffffffu};
-    static constexpr u32 R2[8] = {0x0000000fu, 0x8c78ecb3u, 0x8b0de0e7u, 0xd7d30dbdu,
-                                  0xc3c95d18u, 0x7797a99bu, 0x7b9cb714u, 0x096d41afu};
+// 256-bit packed element as it lives in HBM / at the ABI (8 x u32 little-endian).
+struct alignas(16) fe256 {
+    u32 w[8];
 };
-template <> struct Mod<1> {
-    static constexpr u32 M1 = 0x8c46eb21u, M2 = 0x0994a8ddu, M3 = 0x224698fcu;
-    static constexpr u32 R1[8] = {0xfffffffdu, 0x5b2b3e9cu, 0xe3420567u, 0x992c350bu,
-                                  0xffffffffu, 0xffffffffu, 0xffffffffu, 0x3fffffffu};
-    static constexpr u32 R2[8] = {0x0000000fu, 0xfc9678ffu, 0x891a16e3u, 0x67bb433du,
-                                  0x04ccf590u, 0x7fae2310u, 0x7ccfdaa9u, 0x096d41afu};
-};
-static constexpr u32 MOD_TOP = 0x40000000u;  // limb 7 of both moduli
 
-template <int F> REEF_HD u32 mod_limb(int i) {
-    return i == 0 ? 1u : i == 1 ? Mod<F>::M1 : i == 2 ? Mod<F>::M2 : i == 3 ? Mod<F>::M3 : i == 7 ? MOD_TOP : 0u;
-}
+#if defined(REEF_BOUNDS)
+#define REEF_SET_BOUND(x, b) ((x).bound = (b))
+#define REEF_GET_BOUND(x) ((x).bound)
+#else
+#define REEF_SET_BOUND(x, b) ((void)0)
+#define REEF_GET_BOUND(x) (0.0)
+#endif
 
-REEF_HD bool fe_is_zero(const fe &a) {
-    return (a.v[0] | a.v[1] | a.v[2] | a.v[3] | a.v[4] | a.v[5] | a.v[6] | a.v[7]) == 0;
-}
-REEF_HD bool fe_eq(const fe &a, const fe &b) {
-    u32 d = 0;
-#pragma unroll
-    for (int i = 0; i < 8; ++i) d |= a.v[i] ^ b.v[i];
-    return d == 0;
-}
 REEF_HD fe fe_zero() {
     fe r;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) r.v[i] = 0;
+    for (int i = 0; i < 9; ++i) r.l[i] = 0;
+    REEF_SET_BOUND(r, 0.0);
     return r;
 }
-template <int F> REEF_HD fe fe_one() {  // Montgomery one
+template <int F> REEF_HD fe fe_const(const u32 (&c)[9], double bound) {
     fe r;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) r.v[i] = Mod<F>::R1[i];
+    for (int i = 0; i < 9; ++i) r.l[i] = c[i];
+    REEF_SET_BOUND(r, bound);
+    (void)bound;
     return r;
 }
+template <int F> REEF_HD fe fe_one() { return fe_const<F>(FC<F>::ONE, 1.0); }
+
 REEF_HD fe fe_select(bool c, const fe &a, const fe &b) {  // c ? a : b
     fe r;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) r.v[i] = c ? a.v[i] : b.v[i];
+    for (int i = 0; i < 9; ++i) r.l[i] = c ? a.l[i] : b.l[i];
+#if defined(REEF_BOUNDS)
+    r.bound = a.bound > b.bound ? a.bound : b.bound;
+#endif
     return r;
 }
 
-// r = a - M if a >= M else a      (a < 2^256)
-template <int F> REEF_HD fe fe_reduce_once(const fe &a) {
-    fe d;
-    u64 borrow = 0;
+// Parallel carry: limbs < 2^32 in, limbs l1..l7 <= 2^29 + 7 and l0 < 2^29 out (same value).
+REEF_HD fe fe_norm(const fe &a) {
+    fe r;
+    r.l[0] = a.l[0] & LIMB_MASK;
+#pragma unroll
+    for (int i = 1; i < 8; ++i) r.l[i] = (a.l[i] & LIMB_MASK) + (a.l[i - 1] >> LIMB_BITS);
+    r.l[8] = a.l[8] + (a.l[7] >> LIMB_BITS);
+#if defined(REEF_BOUNDS)
+    r.bound = a.bound;
+    if ((u64)a.l[8] + (a.l[7] >> LIMB_BITS) >= (1ull << 29)) REEF_BOUND_FAIL("top limb overflow in fe_norm");
+#endif
+    return r;
+}
+
+// Sequential carry: every limb < 2^29 exactly (top limb holds the rest).
+REEF_HD fe fe_norm_strict(const fe &a) {
+    fe r;
+    u32 c = 0;
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
-        u64 x = (u64)a.v[i] - mod_limb<F>(i) - borrow;
-        d.v[i] = (u32)x;
-        borrow = (x >> 32) & 1;
+        u32 t = a.l[i] + c;  // limbs < 2^32 - 8 by the caller's contract
+        r.l[i] = t & LIMB_MASK;
+        c = t >> LIMB_BITS;
     }
-    return fe_select(borrow != 0, a, d);
+    r.l[8] = a.l[8] + c;
+#if defined(REEF_BOUNDS)
+    r.bound = a.bound;
+#endif
+    return r;
 }
 
 template <int F> REEF_HD fe fe_add(const fe &a, const fe &b) {
     fe s;
-    u64 c = 0;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        u64 x = (u64)a.v[i] + b.v[i] + c;
-        s.v[i] = (u32)x;
-        c = x >> 32;
-    }
-    return fe_reduce_once<F>(s);  // a, b < M < 2^255: no carry out of limb 7
+    for (int i = 0; i < 9; ++i) s.l[i] = a.l[i] + b.l[i];
+    REEF_SET_BOUND(s, REEF_GET_BOUND(a) + REEF_GET_BOUND(b));
+    return fe_norm(s);
 }
-
-template <int F> REEF_HD fe fe_sub(const fe &a, const fe &b) {
-    fe d, e;
-    u64 borrow = 0;
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        u64 x = (u64)a.v[i] - b.v[i] - borrow;
-        d.v[i] = (u32)x;
-        borrow = (x >> 32) & 1;
-    }
-    u64 c = 0;
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        u64 x = (u64)d.v[i] + mod_limb<F>(i) + c;
-        e.v[i] = (u32)x;
-        c = x >> 32;
-    }
-    return fe_select(borrow != 0, e, d);
-}
-
-template <int F> REEF_HD fe fe_neg(const fe &a) {
-    fe d;
-    u64 borrow = 0;
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        u64 x = (u64)mod_limb<F>(i) - a.v[i] - borrow;
-        d.v[i] = (u32)x;
-        borrow = (x >> 32) & 1;
-    }
-    return fe_select(fe_is_zero(a), a, d);
-}
-
 template <int F> REEF_HD fe fe_dbl(const fe &a) { return fe_add<F>(a, a); }
 
-// One CIOS reduction round on the 9-limb accumulator t (t < 2^288): t = (t + q*M) / 2^32
-// with q = -t0 mod 2^32.
-template <int F> REEF_HD void mont_round(u32 (&t)[9]) {
-    const u32 q = 0u - t[0];
-    u64 c = (t[0] != 0) ? 1u : 0u;  // t0 + q*1 == 2^32 (or 0)
-    u64 x;
-    x = (u64)q * Mod<F>::M1 + t[1] + c; t[0] = (u32)x; c = x >> 32;
-    x = (u64)q * Mod<F>::M2 + t[2] + c; t[1] = (u32)x; c = x >> 32;
-    x = (u64)q * Mod<F>::M3 + t[3] + c; t[2] = (u32)x; c = x >> 32;
-    x = (u64)t[4] + c; t[3] = (u32)x; c = x >> 32;
-    x = (u64)t[5] + c; t[4] = (u32)x; c = x >> 32;
-    x = (u64)t[6] + c; t[5] = (u32)x; c = x >> 32;
-    x = ((u64)q << 30) + t[7] + c; t[6] = (u32)x; c = x >> 32;  // q * 2^30 at limb 7
-    x = (u64)t[8] + c; t[7] = (u32)x; t[8] = (u32)(x >> 32);
+template <int F, int K> REEF_HD const u32 (&fe_bias())[9] {
+    static_assert(K == 2 || K == 4 || K == 8 || K == 16 || K == 32, "bias");
+    if constexpr (K == 2) return FC<F>::BIAS2;
+    else if constexpr (K == 4) return FC<F>::BIAS4;
+    else if constexpr (K == 8) return FC<F>::BIAS8;
+    else if constexpr (K == 16) return FC<F>::BIAS16;
+    else return FC<F>::BIAS32;
 }
 
-// Montgomery product a*b*R^-1 mod M, inputs and output fully reduced.
+// a + K*M - b, normalised.  Requires b < K*M (top limb of b <= top limb of the bias) and
+// limbs of b < 2^31 - 4, limbs of a <= 2^29 + 7.
+template <int F, int K> REEF_HD fe fe_sub(const fe &a, const fe &b) {
+    fe d;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) d.l[i] = a.l[i] + fe_bias<F, K>()[i] - b.l[i];
+#if defined(REEF_BOUNDS)
+    if (b.bound > (double)K * (1.0 - 1e-5)) REEF_BOUND_FAIL("fe_sub: subtrahend bound exceeds the bias");
+    for (int i = 0; i < 9; ++i) {
+        i64 t = (i64)a.l[i] + (i64)fe_bias<F, K>()[i] - (i64)b.l[i];
+        if (t < 0 || t >= (1ll << 32)) REEF_BOUND_FAIL("fe_sub: limb out of range");
+    }
+    d.bound = a.bound + K;
+#endif
+    return fe_norm(d);
+}
+template <int F, int K> REEF_HD fe fe_neg(const fe &a) { return fe_sub<F, K>(fe_zero(), a); }
+
+// Montgomery product a*b/R' mod M.  Inputs normalised with (A/M)*(B/M) < 128; output has exact
+// 29-bit limbs and value < 2M.
 template <int F> REEF_HD fe fe_mul(const fe &a, const fe &b) {
-    u32 t[9];
+#if defined(REEF_BOUNDS)
+    if (a.bound * b.bound >= 128.0) REEF_BOUND_FAIL("fe_mul: (A/M)(B/M) >= 128");
+    for (int i = 0; i < 8; ++i)
+        if (a.l[i] > LIMB_MASK + 8 || b.l[i] > LIMB_MASK + 8) REEF_BOUND_FAIL("fe_mul: operand not normalised");
+#endif
+    u64 t[10];
 #pragma unroll
-    for (int i = 0; i < 9; ++i) t[i] = 0;
+    for (int i = 0; i < 10; ++i) t[i] = 0;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        u64 c = 0;
+    for (int i = 0; i < 9; ++i) {
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            u64 x = (u64)a.v[j] * b.v[i] + t[j] + c;
-            t[j] = (u32)x;
-            c = x >> 32;
-        }
-        t[8] += (u32)c;  // t < 2M before the row, so limb 8 cannot overflow
-        mont_round<F>(t);
+        for (int j = 0; j < 9; ++j) t[j] += (u64)a.l[j] * b.l[i];
+        const u32 q = (0u - (u32)t[0]) & LIMB_MASK;
+        t[0] += q;  // now = 0 mod 2^29
+        t[1] += (u64)q * FC<F>::M1;
+        t[2] += (u64)q * FC<F>::M2;
+        t[3] += (u64)q * FC<F>::M3;
+        t[4] += (u64)q * FC<F>::M4;
+        t[8] += (u64)q << 22;
+        t[1] += t[0] >> LIMB_BITS;
+#pragma unroll
+        for (int j = 0; j < 9; ++j) t[j] = t[j + 1];
+        t[9] = 0;
     }
     fe r;
+    u64 c = 0;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) r.v[i] = t[i];
-    return fe_reduce_once<F>(r);  // t < 2M < 2^256
+    for (int i = 0; i < 8; ++i) {
+        u64 v = t[i] + c;
+        r.l[i] = (u32)v & LIMB_MASK;
+        c = v >> LIMB_BITS;
+    }
+    r.l[8] = (u32)(t[8] + c);
+#if defined(REEF_BOUNDS)
+    if (t[8] + c >= (1ull << 29)) REEF_BOUND_FAIL("fe_mul: result top limb overflow");
+    r.bound = 1.0 + a.bound * b.bound / 128.0;
+#endif
+    return r;
 }
 
-template <int F> REEF_HD fe fe_sqr(const fe &a) { return fe_mul<F>(a, a); }
+// Montgomery square: 45 instead of 81 partial products.
+template <int F> REEF_HD fe fe_sqr(const fe &a) {
+#if defined(REEF_BOUNDS)
+    if (a.bound * a.bound >= 128.0) REEF_BOUND_FAIL("fe_sqr: (A/M)^2 >= 128");
+    for (int i = 0; i < 8; ++i)
+        if (a.l[i] > LIMB_MASK + 8) REEF_BOUND_FAIL("fe_sqr: operand not normalised");
+#endif
+    u32 a2[9];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) a2[i] = a.l[i] << 1;
+    u64 t[10];
+#pragma unroll
+    for (int i = 0; i < 10; ++i) t[i] = 0;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) {
+        // row i holds columns i .. i+8 in t[0..8]; products a_i*a_j (j >= i) land at column i+j
+        t[i - i + i] += 0;  // (keeps the indexing explicit: relative slot of column i+j is j)
+#pragma unroll
+        for (int j = i; j < 9; ++j) t[j] += (u64)a.l[i] * (j == i ? a.l[j] : a2[j]);
+        const u32 q = (0u - (u32)t[0]) & LIMB_MASK;
+        t[0] += q;
+        t[1] += (u64)q * FC<F>::M1;
+        t[2] += (u64)q * FC<F>::M2;
+        t[3] += (u64)q * FC<F>::M3;
+        t[4] += (u64)q * FC<F>::M4;
+        t[8] += (u64)q << 22;
+        t[1] += t[0] >> LIMB_BITS;
+#pragma unroll
+        for (int j = 0; j < 9; ++j) t[j] = t[j + 1];
+        t[9] = 0;
+    }
+    fe r;
+    u64 c = 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        u64 v = t[i] + c;
+        r.l[i] = (u32)v & LIMB_MASK;
+        c = v >> LIMB_BITS;
+    }
+    r.l[8] = (u32)(t[8] + c);
+#if defined(REEF_BOUNDS)
+    if (t[8] + c >= (1ull << 29)) REEF_BOUND_FAIL("fe_sqr: result top limb overflow");
+    r.bound = 1.0 + a.bound * a.bound / 128.0;
+#endif
+    return r;
+}
 
-// Montgomery -> canonical (multiply by 1): 8 reduction rounds only.
-template <int F> REEF_HD fe fe_from_mont(const fe &a) {
-    u32 t[9];
+// Limbs of j*M (strict), j < 64.
+template <int F> REEF_HD fe fe_small_multiple(u32 j) {
+    fe r;
+    u64 c = 0;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) t[i] = a.v[i];
-    t[8] = 0;
+    for (int i = 0; i < 8; ++i) {
+        u64 v = (u64)j * FC<F>::MOD[i] + c;
+        r.l[i] = (u32)v & LIMB_MASK;
+        c = v >> LIMB_BITS;
+    }
+    r.l[8] = (u32)((u64)j * FC<F>::MOD[8] + c);
+    REEF_SET_BOUND(r, (double)j);
+    return r;
+}
+
+// a == 0 (mod M) for a normalised a with value < 64*M.  j*M = j mod 2^29, so the low limb
+// decides almost always; the exact comparison runs on a rare, divergent path.
+template <int F> REEF_HD bool fe_is_zero(const fe &a) {
+#if defined(REEF_BOUNDS)
+    if (a.bound >= 64.0) REEF_BOUND_FAIL("fe_is_zero: bound >= 64");
+#endif
+    const u32 j = a.l[0];
+    if (__builtin_expect(j >= 64u, 1)) return false;
+    const fe s = fe_norm_strict(a);
+    const fe m = fe_small_multiple<F>(j);
+    u32 d = 0;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) mont_round<F>(t);
+    for (int i = 0; i < 9; ++i) d |= s.l[i] ^ m.l[i];
+    return d == 0;
+}
+// exact all-limbs-zero test (the canonical encoding of the point at infinity)
+REEF_HD bool fe_is_literal_zero(const fe &a) {
+    u32 d = 0;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) d |= a.l[i];
+    return d == 0;
+}
+
+// Fully reduced representative: strict limbs, value < M.  Input value < 64*M.
+template <int F> REEF_HD fe fe_canon(const fe &a) {
+    const fe s = fe_norm_strict(a);
+    const u32 q = s.l[8] >> 22;  // floor(value / 2^254) >= floor(value / M)
+    fe r;
+    i64 c = 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        i64 v = (i64)s.l[i] - (i64)((u64)q * FC<F>::MOD[i]) + c;
+        r.l[i] = (u32)v & LIMB_MASK;
+        c = v >> LIMB_BITS;  // arithmetic
+    }
+    i64 top = (i64)s.l[8] - (i64)((u64)q * FC<F>::MOD[8]) + c;
+    const bool neg = top < 0;  // q was one too large: add M back
+    u32 cc = 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        u32 v = r.l[i] + (neg ? FC<F>::MOD[i] : 0u) + cc;
+        r.l[i] = v & LIMB_MASK;
+        cc = v >> LIMB_BITS;
+    }
+    r.l[8] = (u32)(top + (neg ? (i64)FC<F>::MOD[8] : 0) + cc);
+    REEF_SET_BOUND(r, 1.0);
+    return r;
+}
+
+// 256-bit packed (value < 2^256) <-> 9 x 29-bit limbs
+REEF_HD fe fe_unpack(const fe256 &p) {
     fe r;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) r.v[i] = t[i];
-    return fe_reduce_once<F>(r);
+    for (int i = 0; i < 9; ++i) {
+        const int bit = 29 * i, w = bit >> 5, s = bit & 31;
+        u32 v = p.w[w] >> s;
+        if (s > 3 && w + 1 < 8) v |= p.w[w + 1] << (32 - s);
+        r.l[i] = (i == 8) ? v : (v & LIMB_MASK);
+    }
+    REEF_SET_BOUND(r, 4.0);  // any 256-bit value is < 4M; callers that know better overwrite
+    return r;
 }
-
-template <int F> REEF_HD fe fe_to_mont(const fe &a) {
-    fe r2;
+REEF_HD fe256 fe_pack(const fe &a) {  // a strict, value < 2^256
+    fe256 p;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) r2.v[i] = Mod<F>::R2[i];
-    return fe_mul<F>(a, r2);
+    for (int w = 0; w < 8; ++w) {
+        const int bit = 32 * w, i = bit / 29, s = bit - 29 * i;
+        u32 v = a.l[i] >> s;
+        if (i + 1 < 9) v |= a.l[i + 1] << (29 - s);
+        if (29 - s + 29 < 32 && i + 2 < 9) v |= a.l[i + 2] << (58 - s);
+        p.w[w] = v;
+    }
+    return p;
 }
 
-// a^(M-2) (Fermat); inv(0) = 0.  M-2 = 2^254 + (m3:m2:m1:1) - 2.
+// ABI form (Montgomery, R = 2^256, canonical) <-> internal form
+template <int F> REEF_HD fe fe_from_abi(const fe256 &p) {
+    fe x = fe_unpack(p);
+    REEF_SET_BOUND(x, 1.0);  // ABI contract: fully reduced
+    return fe_mul<F>(x, fe_const<F>(FC<F>::C_IN, 1.0));
+}
+template <int F> REEF_HD fe256 fe_to_abi(const fe &a) {
+    return fe_pack(fe_canon<F>(fe_mul<F>(a, fe_const<F>(FC<F>::C_OUT, 1.0))));
+}
+// internal form, canonical, packed: the layout of resident key tables in HBM
+template <int F> REEF_HD fe256 fe_to_table(const fe &a) { return fe_pack(fe_canon<F>(a)); }
+REEF_HD fe fe_from_table(const fe256 &p) {
+    fe x = fe_unpack(p);
+    REEF_SET_BOUND(x, 1.0);
+    return x;
+}
+// Montgomery (R = 2^256) scalar -> canonical integer, packed (what the digit recoder reads):
+// mont(s*2^256, 2^5) = s.
+template <int F> REEF_HD fe256 fe_abi_to_integer(const fe256 &p) {
+    fe x = fe_unpack(p);
+    REEF_SET_BOUND(x, 1.0);
+    fe c32 = fe_zero();
+    c32.l[0] = 32;
+    REEF_SET_BOUND(c32, 1.0);
+    return fe_pack(fe_canon<F>(fe_mul<F>(x, c32)));
+}
+// canonical integer (< M) -> internal form: mont(x, R'^2)
+template <int F> REEF_HD fe fe_from_integer(const fe256 &p) {
+    fe x = fe_unpack(p);
+    REEF_SET_BOUND(x, 1.0);
+    return fe_mul<F>(x, fe_const<F>(FC<F>::C_R2, 1.0));
+}
+
+// a^(M-2); inv(0) = 0.  M - 2 = 2^254 + delta - 2.
 template <int F> REEF_HD fe fe_inv(const fe &a) {
-    // exponent limbs
-    u32 e[8];
-    e[0] = 0xffffffffu;  // 1 - 2 borrows from limb 1
-    e[1] = Mod<F>::M1 - 1u;
-    e[2] = Mod<F>::M2;
-    e[3] = Mod<F>::M3;
-    e[4] = e[5] = e[6] = 0;
-    e[7] = MOD_TOP;
+    // exponent as 9 x 29-bit limbs: MOD with limb0 = 1 - 2 -> borrow from limb 1
+    u32 e[9];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) e[i] = FC<F>::MOD[i];
+    e[0] = LIMB_MASK;  // 1 - 2 + 2^29
+    e[1] -= 1;
     fe acc = fe_one<F>();
     for (int i = 254; i >= 0; --i) {
         acc = fe_sqr<F>(acc);
-        if ((e[i >> 5] >> (i & 31)) & 1) acc = fe_mul<F>(acc, a);
+        const int limb = i / 29, bit = i - 29 * limb;
+        if ((e[limb] >> bit) & 1u) acc = fe_mul<F>(acc, a);
     }
     return acc;
 }

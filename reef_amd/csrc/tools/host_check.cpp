@@ -1,0 +1,84 @@
+// Host build of field.h / ec.h with bound tracking (REEF_BOUNDS): the same formulas the
+// kernels run, executed on the CPU so that `pytest -m "not gpu"` can compare them with the
+// oracle and machine-check every value-bound comment.  TEST HARNESS ONLY -- the product
+// (libreef_msm.so) never links this.
+//   g++ -O2 -std=c++17 -DREEF_BOUNDS -shared -fPIC host_check.cpp -o libreef_hostcheck.so
+#include <string.h>
+
+#include "../ec.h"
+
+using namespace reef;
+
+template <int F> static void field_op(int op, const fe256 *a, const fe256 *b, fe256 *out) {
+    if (op == 4) { *out = fe_to_abi<F>(fe_from_integer<F>(*a)); return; }
+    if (op == 5) { *out = fe_abi_to_integer<F>(*a); return; }
+    const fe x = fe_from_abi<F>(*a), y = fe_from_abi<F>(*b);
+    fe z;
+    switch (op) {
+        case 0: z = fe_mul<F>(x, y); break;
+        case 1: z = fe_add<F>(x, y); break;
+        case 2: z = fe_sub<F, 2>(x, y); break;
+        case 3: z = fe_inv<F>(x); break;
+        case 6: z = fe_neg<F, 2>(x); break;
+        default: z = fe_sqr<F>(x); break;
+    }
+    *out = fe_to_abi<F>(z);
+}
+
+template <int C> static void ec_op(int op, const affine256 *pa, const affine256 *qa, const fe256 *k, jacobian256 *out) {
+    const affine p = affine_from_abi<C>(*pa), q = affine_from_abi<C>(*qa);
+    xyzz r;
+    if (op == 0) r = xyzz_madd<C>(xyzz_from_affine<C>(p), q);
+    else if (op == 1) {
+        xyzz a = xyzz_dbl<C>(xyzz_from_affine<C>(p));
+        a = xyzz_madd<C>(a, affine_neg<C>(p));
+        xyzz b = xyzz_dbl<C>(xyzz_from_affine<C>(q));
+        b = xyzz_madd<C>(b, affine_neg<C>(q));
+        r = xyzz_add<C>(a, b);
+    } else if (op == 2) r = xyzz_dbl<C>(xyzz_from_affine<C>(p));
+    else r = xyzz_scalar_mul<C>(p, k->w, 255);
+    *out = xyzz_to_abi_jacobian<C>(r);
+}
+
+// Bucket-style accumulation chain: acc = sum_i (+/-) pts[i] with the table round trip the
+// kernels use (ABI -> table form -> registers), exercising the steady-state bounds of madd.
+template <int C> static void accumulate(const affine256 *pts, const uint8_t *neg, size_t n, jacobian256 *out, affine256 *out_aff, fe256 *out_comp) {
+    xyzz acc = xyzz_identity();
+    bool empty = true;
+    for (size_t i = 0; i < n; ++i) {
+        const affine256 tab = affine_to_table<C>(affine_from_abi<C>(pts[i]));
+        affine pt = affine_from_table(tab);
+        pt.y = fe_select(neg[i] && !affine_is_inf(pt), fe_neg<C, 2>(pt.y), pt.y);
+        acc = xyzz_madd_flag<C>(acc, empty, pt);
+        empty = false;
+        // round trip through the engine-internal memory form
+        acc = xyzz_from_mem(xyzz_to_mem(acc));
+    }
+    *out = xyzz_to_abi_jacobian<C>(acc);
+    const affine a = xyzz_to_affine<C>(acc);
+    *out_aff = affine_to_abi<C>(a);
+    *out_comp = affine_compress<C>(a);
+}
+
+extern "C" {
+void host_field_op(int field, int op, const void *a, const void *b, void *out, size_t n) {
+    for (size_t i = 0; i < n; ++i) {
+        if (field == 0) field_op<0>(op, (const fe256 *)a + i, (const fe256 *)b + i, (fe256 *)out + i);
+        else field_op<1>(op, (const fe256 *)a + i, (const fe256 *)b + i, (fe256 *)out + i);
+    }
+}
+void host_ec_op(int curve, int op, const void *p, const void *q, const void *k, void *out, size_t n) {
+    for (size_t i = 0; i < n; ++i) {
+        if (curve == 0) ec_op<0>(op, (const affine256 *)p + i, (const affine256 *)q + i, (const fe256 *)k + i, (jacobian256 *)out + i);
+        else ec_op<1>(op, (const affine256 *)p + i, (const affine256 *)q + i, (const fe256 *)k + i, (jacobian256 *)out + i);
+    }
+}
+void host_accumulate(int curve, const void *pts, const uint8_t *neg, size_t n, void *out_jac, void *out_aff, void *out_comp) {
+    if (curve == 0) accumulate<0>((const affine256 *)pts, neg, n, (jacobian256 *)out_jac, (affine256 *)out_aff, (fe256 *)out_comp);
+    else accumulate<1>((const affine256 *)pts, neg, n, (jacobian256 *)out_jac, (affine256 *)out_aff, (fe256 *)out_comp);
+}
+// raw pack/unpack round trip (8 x u32 <-> 9 x 29-bit limbs)
+void host_pack_roundtrip(const void *in, void *out) {
+    *(fe256 *)out = fe_pack(fe_norm_strict(fe_unpack(*(const fe256 *)in)));
+}
+}
