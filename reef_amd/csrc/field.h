@@ -166,8 +166,80 @@ template <int F, int K> REEF_HD fe fe_sub(const fe &a, const fe &b) {
 }
 template <int F, int K> REEF_HD fe fe_neg(const fe &a) { return fe_sub<F, K>(fe_zero(), a); }
 
+#if !defined(__HIP_DEVICE_COMPILE__)
+// Host forms of the row operations (the gfx950 forms are whole rows of v_mad_u64_u32 in one
+// asm statement each: field_mad_gfx950.h).
+REEF_HD void mad_row_new(u64 (&t)[10], const u32 (&a)[9], u32 b) {
+    for (int j = 0; j < 9; ++j) t[j] = (u64)a[j] * b;
+}
+REEF_HD void mad_row_acc(u64 (&t)[10], const u32 (&a)[9], u32 b) {
+    for (int j = 0; j < 8; ++j) t[j] += (u64)a[j] * b;
+    t[8] = (u64)a[8] * b;
+}
+REEF_HD void mad_reduce(u64 (&t)[10], u32 q, u32 m1, u32 m2, u32 m3, u32 m4, u32 top) {
+    t[0] += q;
+    t[1] += (u64)q * m1; t[2] += (u64)q * m2; t[3] += (u64)q * m3; t[4] += (u64)q * m4;
+    t[8] += (u64)q * top;
+}
+template <int I> REEF_HD void sqr_row(u64 (&t)[10], const u32 (&a)[9], const u32 (&a2)[9]) {
+    if (I == 0) {
+        t[0] = (u64)a[0] * a[0];
+        for (int j = 1; j < 9; ++j) t[j] = (u64)a[0] * a2[j];
+    } else if (I == 8) {
+        t[8] = (u64)a[8] * a[8];
+    } else {
+        t[I] += (u64)a[I] * a[I];
+        for (int j = I + 1; j < 8; ++j) t[j] += (u64)a[I] * a2[j];
+        t[8] = (u64)a[I] * a2[8];
+    }
+}
+#else
+}  // namespace reef
+#include "field_mad_gfx950.h"
+namespace reef {
+template <int I> __device__ __forceinline__ void sqr_row(u64 (&t)[10], const u32 (&a)[9], const u32 (&a2)[9]) {
+    if constexpr (I == 0) sqr_row0(t, a, a2);
+    else if constexpr (I == 1) sqr_row1(t, a, a2);
+    else if constexpr (I == 2) sqr_row2(t, a, a2);
+    else if constexpr (I == 3) sqr_row3(t, a, a2);
+    else if constexpr (I == 4) sqr_row4(t, a, a2);
+    else if constexpr (I == 5) sqr_row5(t, a, a2);
+    else if constexpr (I == 6) sqr_row6(t, a, a2);
+    else if constexpr (I == 7) sqr_row7(t, a, a2);
+    else sqr_row8(t, a, a2);
+}
+#endif
+
+// One Montgomery reduction round on the column accumulators t[0..8] (t[0] = current column):
+// q = -t0 mod 2^29, t += q*M, the (now zero) low 29 bits of t[0] are dropped into t[1], and the
+// accumulators are renamed one column up (free after unrolling).
+template <int F> REEF_HD void mont_round(u64 (&t)[10]) {
+    const u32 q = (0u - (u32)t[0]) & LIMB_MASK;
+    mad_reduce(t, q, FC<F>::M1, FC<F>::M2, FC<F>::M3, FC<F>::M4, 1u << 22);
+    t[1] += t[0] >> LIMB_BITS;
+#pragma unroll
+    for (int j = 0; j < 9; ++j) t[j] = t[j + 1];
+}
+
+template <int F> REEF_HD fe mont_finish(const u64 (&t)[10]) {
+    fe r;
+    u64 c = 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const u64 v = t[i] + c;
+        r.l[i] = (u32)v & LIMB_MASK;
+        c = v >> LIMB_BITS;
+    }
+    r.l[8] = (u32)(t[8] + c);
+#if defined(REEF_BOUNDS)
+    if (t[8] + c >= (1ull << 29)) REEF_BOUND_FAIL("Montgomery product: result top limb overflow");
+#endif
+    return r;
+}
+
 // Montgomery product a*b/R' mod M.  Inputs normalised with (A/M)*(B/M) < 128; output has exact
-// 29-bit limbs and value < 2M.
+// 29-bit limbs and value < 2M.  Row i adds a*b_i into columns i..i+8 (t[0..8]) and reduces
+// column i.
 template <int F> REEF_HD fe fe_mul(const fe &a, const fe &b) {
 #if defined(REEF_BOUNDS)
     if (a.bound * b.bound >= 128.0) REEF_BOUND_FAIL("fe_mul: (A/M)(B/M) >= 128");
@@ -175,41 +247,21 @@ template <int F> REEF_HD fe fe_mul(const fe &a, const fe &b) {
         if (a.l[i] > LIMB_MASK + 8 || b.l[i] > LIMB_MASK + 8) REEF_BOUND_FAIL("fe_mul: operand not normalised");
 #endif
     u64 t[10];
+    t[9] = 0;
+    mad_row_new(t, a.l, b.l[0]);
+    mont_round<F>(t);
 #pragma unroll
-    for (int i = 0; i < 10; ++i) t[i] = 0;
-#pragma unroll
-    for (int i = 0; i < 9; ++i) {
-#pragma unroll
-        for (int j = 0; j < 9; ++j) t[j] += (u64)a.l[j] * b.l[i];
-        const u32 q = (0u - (u32)t[0]) & LIMB_MASK;
-        t[0] += q;  // now = 0 mod 2^29
-        t[1] += (u64)q * FC<F>::M1;
-        t[2] += (u64)q * FC<F>::M2;
-        t[3] += (u64)q * FC<F>::M3;
-        t[4] += (u64)q * FC<F>::M4;
-        t[8] += (u64)q << 22;
-        t[1] += t[0] >> LIMB_BITS;
-#pragma unroll
-        for (int j = 0; j < 9; ++j) t[j] = t[j + 1];
-        t[9] = 0;
+    for (int i = 1; i < 9; ++i) {
+        mad_row_acc(t, a.l, b.l[i]);
+        mont_round<F>(t);
     }
-    fe r;
-    u64 c = 0;
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        u64 v = t[i] + c;
-        r.l[i] = (u32)v & LIMB_MASK;
-        c = v >> LIMB_BITS;
-    }
-    r.l[8] = (u32)(t[8] + c);
-#if defined(REEF_BOUNDS)
-    if (t[8] + c >= (1ull << 29)) REEF_BOUND_FAIL("fe_mul: result top limb overflow");
-    r.bound = 1.0 + a.bound * b.bound / 128.0;
-#endif
+    fe r = mont_finish<F>(t);
+    REEF_SET_BOUND(r, 1.0 + REEF_GET_BOUND(a) * REEF_GET_BOUND(b) / 128.0);
     return r;
 }
 
-// Montgomery square: 45 instead of 81 partial products.
+// Montgomery square: 45 instead of 81 partial products (a_i*a_j, i < j, taken once with 2*a_j;
+// row i holds columns i..i+8 in t[0..8], so a_i*a_j lands in slot j).
 template <int F> REEF_HD fe fe_sqr(const fe &a) {
 #if defined(REEF_BOUNDS)
     if (a.bound * a.bound >= 128.0) REEF_BOUND_FAIL("fe_sqr: (A/M)^2 >= 128");
@@ -220,39 +272,18 @@ template <int F> REEF_HD fe fe_sqr(const fe &a) {
 #pragma unroll
     for (int i = 0; i < 9; ++i) a2[i] = a.l[i] << 1;
     u64 t[10];
-#pragma unroll
-    for (int i = 0; i < 10; ++i) t[i] = 0;
-#pragma unroll
-    for (int i = 0; i < 9; ++i) {
-        // row i holds columns i .. i+8 in t[0..8]; products a_i*a_j (j >= i) land at column i+j
-        t[i - i + i] += 0;  // (keeps the indexing explicit: relative slot of column i+j is j)
-#pragma unroll
-        for (int j = i; j < 9; ++j) t[j] += (u64)a.l[i] * (j == i ? a.l[j] : a2[j]);
-        const u32 q = (0u - (u32)t[0]) & LIMB_MASK;
-        t[0] += q;
-        t[1] += (u64)q * FC<F>::M1;
-        t[2] += (u64)q * FC<F>::M2;
-        t[3] += (u64)q * FC<F>::M3;
-        t[4] += (u64)q * FC<F>::M4;
-        t[8] += (u64)q << 22;
-        t[1] += t[0] >> LIMB_BITS;
-#pragma unroll
-        for (int j = 0; j < 9; ++j) t[j] = t[j + 1];
-        t[9] = 0;
-    }
-    fe r;
-    u64 c = 0;
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        u64 v = t[i] + c;
-        r.l[i] = (u32)v & LIMB_MASK;
-        c = v >> LIMB_BITS;
-    }
-    r.l[8] = (u32)(t[8] + c);
-#if defined(REEF_BOUNDS)
-    if (t[8] + c >= (1ull << 29)) REEF_BOUND_FAIL("fe_sqr: result top limb overflow");
-    r.bound = 1.0 + a.bound * a.bound / 128.0;
-#endif
+    t[9] = 0;
+    sqr_row<0>(t, a.l, a2); mont_round<F>(t);
+    sqr_row<1>(t, a.l, a2); mont_round<F>(t);
+    sqr_row<2>(t, a.l, a2); mont_round<F>(t);
+    sqr_row<3>(t, a.l, a2); mont_round<F>(t);
+    sqr_row<4>(t, a.l, a2); mont_round<F>(t);
+    sqr_row<5>(t, a.l, a2); mont_round<F>(t);
+    sqr_row<6>(t, a.l, a2); mont_round<F>(t);
+    sqr_row<7>(t, a.l, a2); mont_round<F>(t);
+    sqr_row<8>(t, a.l, a2); mont_round<F>(t);
+    fe r = mont_finish<F>(t);
+    REEF_SET_BOUND(r, 1.0 + REEF_GET_BOUND(a) * REEF_GET_BOUND(a) / 128.0);
     return r;
 }
 
