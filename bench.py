@@ -111,7 +111,7 @@ def main():
     k0, d = 0xABCDEF, 0x12345
     kind = 0 if a.scalars == "uniform" else 1
     seed = 0x5EEF + rank
-    groups = a.bucket_groups if a.bucket_groups >= 0 else 0
+    groups = a.bucket_groups if a.bucket_groups >= 0 else 1   # bench key: full precompute (fixed commitment key)
 
     # synthetic inputs, generated on the device: rank r owns bases B_i, i in [r*n, (r+1)*n)
     bases = msm.gen_bases(a.curve, k0 + rank * n * d, d, n, device=True)

@@ -1,0 +1,168 @@
+"""Host-side mirror of the nova-snark provider interface that Reef calls for its commitments.
+
+Reef itself defines no plugin/FFI interface for this path: it calls the Rust
+generics of nova-snark (git dep sga001/Nova, not vendored).  This module mirrors the *names and
+argument meaning* of the pieces Reef reaches, on top of the C ABI, so that tests read like the
+reference's call sites and so that a maintainer can see what each Rust method maps to:
+
+    reference call site (eniac/Reef)                         here
+    -------------------------------------------------------  --------------------------------
+    G::vartime_multiscalar_mul(scalars, bases)        [R]    vartime_multiscalar_mul(...)
+    CommitmentGens::<G>::new(label, n) / new_with_..  [R]    CommitmentGens(curve, bases [, h])
+        (framework.rs:297-303, commitment.rs:176-180)         (bases are *given*: key derivation
+                                                               from_label is row N1 of SURVEY 8f)
+    CE::commit(&gens, &v, &blind)                      [R]    CommitmentGens.commit(v, blind)
+        (commitment.rs:350,361,422,430)
+    gens.fold(w1, w2) / split_at / combine             [R]    CommitmentGens.fold / split_at / combine
+        (ipa_pc inside CompressedSNARK::prove, framework.rs:695)
+    HyraxPC::commit(&poly)                             [R]    HyraxPC.commit(poly)
+        (commitment.rs:187)
+    Commitment::compress()                             [R]    Commitment.compress()
+        (commitment.rs:195,351,365,425,427,431)
+
+[R] = recalled interface of an un-vendored crate; errors follow the reference's convention
+(`assert!`/`panic!` there, exceptions here).  All group arithmetic runs in libreef_msm.so.
+"""
+from __future__ import annotations
+
+from typing import Optional, Sequence, Tuple
+
+import numpy as np
+
+from . import msm
+
+MODULI = {
+    # scalar field of each curve (Pallas scalars live in Fq = the modulus Reef hard-codes at
+    # src/backend/r1cs_helper.rs:37-38)
+    msm.PALLAS: 0x40000000000000000000000000000000224698FC0994A8DD8C46EB2100000001,
+    msm.VESTA: 0x40000000000000000000000000000000224698FC094CF91B992D30ED00000001,
+}
+
+
+def scalars_to_array(values: Sequence[int], curve) -> np.ndarray:
+    """Canonical Python ints -> (n, 4) uint64 canonical limbs (pass is_mont=False downstream)."""
+    q = MODULI[msm.curve_id(curve)]
+    out = np.zeros((len(values), 4), dtype=np.uint64)
+    for i, v in enumerate(values):
+        v %= q
+        for j in range(4):
+            out[i, j] = (v >> (64 * j)) & 0xFFFFFFFFFFFFFFFF
+    return out
+
+
+class Commitment:
+    """A group element as the engine returns it (Jacobian, ABI layout)."""
+
+    def __init__(self, curve, jac: np.ndarray):
+        self.curve = msm.curve_id(curve)
+        self.jac = np.ascontiguousarray(jac, dtype=np.uint64).reshape(12)
+
+    def compress(self) -> bytes:
+        return msm.compress(self.curve, self.jac)
+
+    def to_affine(self) -> np.ndarray:
+        return msm.normalize(self.curve, self.jac)[0][0]
+
+    def __eq__(self, other) -> bool:  # equality on the canonical encoding, like the Rust side
+        return isinstance(other, Commitment) and self.curve == other.curve and self.compress() == other.compress()
+
+    def __add__(self, other: "Commitment") -> "Commitment":
+        assert self.curve == other.curve
+        return Commitment(self.curve, msm.sum_points(self.curve, np.stack([self.jac, other.jac])))
+
+
+def vartime_multiscalar_mul(curve, scalars: np.ndarray, bases: np.ndarray, is_mont: bool = True) -> Commitment:
+    """Group::vartime_multiscalar_mul: stateless, through the pasta-msm drop-in symbol."""
+    if len(scalars) != len(bases):
+        raise ValueError("scalars and bases differ in length")  # the Rust wrapper panics
+    return Commitment(curve, msm.mult_pippenger(curve, bases, scalars, is_mont=is_mont))
+
+
+class CommitmentGens:
+    """nova-snark `CommitmentGens<G>`: a vector of generators (+ optional blinding generator h)
+    resident on the GPU."""
+
+    def __init__(self, curve, bases: np.ndarray, h: Optional[np.ndarray] = None, *, precompute: bool = True,
+                 window_bits: int = 0):
+        self.curve = msm.curve_id(curve)
+        self.bases = np.ascontiguousarray(bases, dtype=np.uint64).reshape(-1, 8)
+        self.h = None if h is None else np.ascontiguousarray(h, dtype=np.uint64).reshape(8)
+        self._precompute = precompute
+        self._window_bits = window_bits
+        self._ctx: Optional[msm.MsmContext] = None
+
+    def __len__(self) -> int:
+        return self.bases.shape[0]
+
+    def _context(self) -> msm.MsmContext:
+        if self._ctx is None:
+            self._ctx = msm.MsmContext(self.curve, self.bases, window_bits=self._window_bits,
+                                       bucket_groups=1 if self._precompute else 0)
+        return self._ctx
+
+    def close(self) -> None:
+        if self._ctx is not None:
+            self._ctx.close()
+            self._ctx = None
+
+    # CE::commit(&gens, &v, &blind)
+    def commit(self, v: np.ndarray, blind: Optional[np.ndarray] = None, *, is_mont: bool = True) -> Commitment:
+        v = np.ascontiguousarray(v, dtype=np.uint64).reshape(-1, 4)
+        if v.shape[0] > len(self):
+            raise ValueError(f"vector of {v.shape[0]} scalars exceeds {len(self)} generators")
+        if blind is None:
+            return Commitment(self.curve, self._context().msm(v, is_mont=is_mont))
+        if self.h is None:
+            raise ValueError("these generators have no blinding generator")
+        b = np.ascontiguousarray(blind, dtype=np.uint64).reshape(1, 4)
+        out = self._context().msm_rows(v, 1, v.shape[0], is_mont=is_mont, blinds=b, h=self.h)
+        return Commitment(self.curve, out[0])
+
+    # gens.fold(w1, w2): G'_i = w1*G_i + w2*G_{n/2+i}
+    def fold(self, w1: int, w2: int) -> "CommitmentGens":
+        n = len(self)
+        if n % 2:
+            raise ValueError("fold needs an even number of generators")
+        folded = msm.fold(self.curve, self.bases, n // 2, w1, w2)
+        return CommitmentGens(self.curve, folded, self.h, precompute=False)
+
+    def split_at(self, k: int) -> Tuple["CommitmentGens", "CommitmentGens"]:
+        return (CommitmentGens(self.curve, self.bases[:k].copy(), self.h, precompute=False),
+                CommitmentGens(self.curve, self.bases[k:].copy(), self.h, precompute=False))
+
+    def combine(self, other: "CommitmentGens") -> "CommitmentGens":
+        assert self.curve == other.curve
+        return CommitmentGens(self.curve, np.concatenate([self.bases, other.bases]), self.h, precompute=False)
+
+
+class HyraxPC:
+    """nova-snark `HyraxPC` as Reef builds it at src/backend/commitment.rs:182-185: row generators
+    `gens_v` (2^right of them) with the blinding generator of `gens_s`."""
+
+    def __init__(self, gens_v: CommitmentGens):
+        if gens_v.h is None:
+            raise ValueError("HyraxPC needs a blinding generator")
+        self.gens_v = gens_v
+
+    @staticmethod
+    def compute_factored_lens(num_vars: int) -> Tuple[int, int]:
+        """EqPolynomial::compute_factored_lens [R]: (left, right) = (l/2, l - l/2)."""
+        return num_vars // 2, num_vars - num_vars // 2
+
+    def commit(self, poly: np.ndarray, blinds: np.ndarray, *, is_mont: bool = True, max_scalar_bits: int = 0):
+        """HyraxPC::commit(&poly): the 2^l evaluations are viewed as an L x R matrix (L = 2^left
+        rows); returns the L row commitments  sum_j Z[i, j] * G_j + blinds[i] * H  and their
+        32-byte compressed forms (what Reef absorbs into the Poseidon RO, commitment.rs:190-198)."""
+        poly = np.ascontiguousarray(poly, dtype=np.uint64).reshape(-1, 4)
+        n = poly.shape[0]
+        if n & (n - 1):
+            raise ValueError("polynomial length must be a power of two")
+        left, right = self.compute_factored_lens(n.bit_length() - 1)
+        rows, row_len = 1 << left, 1 << right
+        if row_len > len(self.gens_v):
+            raise ValueError("not enough row generators")
+        blinds = np.ascontiguousarray(blinds, dtype=np.uint64).reshape(rows, 4)
+        out = self.gens_v._context().msm_rows(poly, rows, row_len, is_mont=is_mont, max_scalar_bits=max_scalar_bits,
+                                              blinds=blinds, h=self.gens_v.h)
+        comp = msm.normalize(self.gens_v.curve, out, affine=False, compressed=True)[1]
+        return out, comp

@@ -1,0 +1,89 @@
+"""The provider mirror (reef_amd/provider.py) exercised the way Reef's call sites use nova-snark:
+CE::commit with a blind (commitment.rs:350,361), the hybrid equality relation
+(commitment.rs:407-444, test eq_proof :633-680), HyraxPC::commit (commitment.rs:187) and one IPA
+round's generator fold + the two cross MSMs (framework.rs:695)."""
+import numpy as np
+import pytest
+
+from oracle.pasta_oracle import CURVES, SplitMix64, uniform_scalar
+
+pytestmark = pytest.mark.gpu
+
+
+def limbs(v):
+    return [(v >> (64 * i)) & 0xFFFFFFFFFFFFFFFF for i in range(4)]
+
+
+def test_commit_with_blind_is_homomorphic(gpu_lib, cref):
+    """eq_proof shape: C1 = v*G + r1*H, C2 = v*G + r2*H  =>  C1 - C2 = (r1 - r2)*H."""
+    from reef_amd import provider as P
+    C = CURVES["pallas"]
+    G = cref.gen_bases_ap(0, 5, 1, 1)
+    H = cref.gen_bases_ap(0, 0xB11D, 1, 1)[0]
+    gens = P.CommitmentGens("pallas", G, H)
+    rng = SplitMix64(1)
+    v, r1, r2 = (uniform_scalar(rng, C.order) for _ in range(3))
+    c1 = gens.commit(P.scalars_to_array([v], "pallas"), P.scalars_to_array([r1], "pallas")[0], is_mont=False)
+    c2 = gens.commit(P.scalars_to_array([v], "pallas"), P.scalars_to_array([r2], "pallas")[0], is_mont=False)
+    g, h = C.affine_from_bytes(G[0].tobytes()), C.affine_from_bytes(H.tobytes())
+    assert c1.compress() == C.compress(C.add(C.mul(v, g), C.mul(r1, h)))
+    assert c2.compress() == C.compress(C.add(C.mul(v, g), C.mul(r2, h)))
+    hgens = P.CommitmentGens("pallas", H.reshape(1, 8))
+    diff = hgens.commit(P.scalars_to_array([(r1 - r2) % C.order], "pallas"), is_mont=False)
+    neg_c2 = P.Commitment("pallas", c2.jac.copy())
+    # -C2: negate y of the affine form and re-wrap
+    aff = neg_c2.to_affine()
+    pt = C.neg(C.affine_from_bytes(aff.tobytes()))
+    j = np.zeros(12, dtype=np.uint64)
+    j[:8] = np.frombuffer(C.affine_to_bytes(pt), dtype=np.uint64)
+    j[8:] = cref.field_op("to_mont", 0, cref.int_to_limbs(1))
+    assert (c1 + P.Commitment("pallas", j)) == diff
+    gens.close(); hgens.close()
+
+
+def test_hyrax_commit_matches_oracle(gpu_lib, cref):
+    from reef_amd import provider as P
+    for name, cid, bound in (("pallas", 0, 7), ("pallas", 0, 131), ("vesta", 1, 131)):
+        num_vars = 13                               # 8192 symbols -> 64 rows x 128 columns
+        left, right = P.HyraxPC.compute_factored_lens(num_vars)
+        assert (left, right) == (6, 7)
+        rows, row_len = 1 << left, 1 << right
+        gens_v = P.CommitmentGens(name, cref.gen_bases_ap(cid, 9, 2, row_len), cref.gen_bases_ap(cid, 0xB11D, 1, 1)[0])
+        poly = cref.gen_scalars(cid, 7, rows * row_len, kind=2, small_bound=bound)
+        blinds = cref.gen_scalars(cid, 8, rows)
+        out, comp = P.HyraxPC(gens_v).commit(poly, blinds)
+        exp = cref.row_msm(cid, gens_v.bases, poly, rows, row_len, h=gens_v.h, blinds=blinds, threads=4)
+        assert comp.tobytes() == cref.compress(cid, exp)
+        gens_v.close()
+
+
+def test_ipa_round_shape(gpu_lib, cref):
+    """One round of the inner-product argument as nova's ipa_pc runs it: L = <a_lo, G_hi>,
+    R = <a_hi, G_lo> (two MSMs of n/2 points with changing bases), then G' = fold(G, r^-1, r)."""
+    from reef_amd import provider as P
+    cid, name = 0, "pallas"
+    C = CURVES[name]
+    n = 512
+    gens = P.CommitmentGens(name, cref.gen_bases_ap(cid, 21, 4, n), precompute=False)
+    a = cref.gen_scalars(cid, 3, n, mont=False)
+    g_lo, g_hi = gens.split_at(n // 2)
+    L = g_hi.commit(a[: n // 2].copy(), is_mont=False)
+    Rr = g_lo.commit(a[n // 2:].copy(), is_mont=False)
+    assert L.compress() == cref.compress(cid, cref.msm_pippenger(cid, g_hi.bases, a[: n // 2].copy(), mont=False))
+    assert Rr.compress() == cref.compress(cid, cref.msm_pippenger(cid, g_lo.bases, a[n // 2:].copy(), mont=False))
+    r = 0x1234567890ABCDEF1234567890ABCDEF % C.order
+    rinv = pow(r, -1, C.order)
+    folded = gens.fold(rinv, r)
+    assert (folded.bases == cref.fold(cid, gens.bases, rinv, r)).all()
+    assert len(g_lo.combine(g_hi)) == n
+    # folded commitment relation: <a', G'> with a' = r*a_lo + r^-1*a_hi  equals  C + r^2 L + r^-2 R
+    alo = [cref.limbs_to_int(x) for x in a[: n // 2]]
+    ahi = [cref.limbs_to_int(x) for x in a[n // 2:]]
+    a2 = P.scalars_to_array([(r * x + rinv * y) % C.order for x, y in zip(alo, ahi)], name)
+    lhs = folded.commit(a2, is_mont=False)
+    Cfull = gens.commit(a, is_mont=False)
+    def scale(cm, k):
+        aff = cm.to_affine().reshape(1, 8)
+        return P.CommitmentGens(name, aff, precompute=False).commit(P.scalars_to_array([k], name), is_mont=False)
+    rhs = Cfull + scale(L, r * r % C.order) + scale(Rr, rinv * rinv % C.order)
+    assert lhs == rhs
