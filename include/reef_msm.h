@@ -83,6 +83,10 @@ typedef struct {
 
 reef_status reef_msm_ctx_create(reef_msm_ctx **out, int curve, const reef_affine *bases, size_t n,
                                 int bases_loc, const reef_msm_opts *opts /* may be NULL */);
+/* Replace the key of a ctx in place (same options, workspace kept): what the IPA rounds need, where
+ * the generators change every round (CommitmentGens::fold [R], framework.rs:695).  Fails on a ctx
+ * whose key is shared with clones. */
+reef_status reef_msm_ctx_set_bases(reef_msm_ctx *ctx, const reef_affine *bases, size_t n, int bases_loc);
 /* A second handle on the same resident key with its own stream and workspace (for callers that
  * issue MSMs from several threads, e.g. nova's rayon workers inside ipa_pc). */
 reef_status reef_msm_ctx_clone(reef_msm_ctx **out, reef_msm_ctx *src);

@@ -59,6 +59,7 @@ def load() -> ctypes.CDLL:
         "mult_pippenger_vesta": (None, [vp, vp, c_size_t, vp, c_bool]),
         "reef_msm_ctx_create": (c_int, [POINTER(vp), c_int, vp, c_size_t, c_int, POINTER(MsmOpts)]),
         "reef_msm_ctx_clone": (c_int, [POINTER(vp), vp]),
+        "reef_msm_ctx_set_bases": (c_int, [vp, vp, c_size_t, c_int]),
         "reef_msm_ctx_destroy": (None, [vp]),
         "reef_msm_ctx_sync": (c_int, [vp]),
         "reef_msm_ctx_stream": (vp, [vp]),

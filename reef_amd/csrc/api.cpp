@@ -108,6 +108,10 @@ reef_status reef_msm_ctx_create(reef_msm_ctx **out, int curve, const reef_affine
     *out = new reef_msm_ctx{curve, impl};
     return REEF_OK;
 }
+reef_status reef_msm_ctx_set_bases(reef_msm_ctx *ctx, const reef_affine *bases, size_t n, int bases_loc) {
+    if (!ctx || (n && !bases)) { set_error("null argument"); return REEF_ERR_ARG; }
+    return vt(ctx->curve)->ctx_rekey(ctx->impl, bases, n, bases_loc);
+}
 reef_status reef_msm_ctx_clone(reef_msm_ctx **out, reef_msm_ctx *src) {
     if (!out || !src) { set_error("null argument"); return REEF_ERR_ARG; }
     void *impl = nullptr;

@@ -1,0 +1,180 @@
+// reef_replay -- issues, through the C ABI only, the MSM sequence of one `reef --prove` run
+// (eniac/Reef src/backend/framework.rs:642-754) with synthetic scalars of the right shapes, and
+// times it.  Reef itself is Rust and cannot be built in this image (no cargo, crates not
+// vendored), so the "--prove" numbers of this backend are REPLAYS of the commitment work, never
+// an end-to-end proof: NFA construction, witness generation and sum-checks stay on the host and
+// are not part of what is timed here.
+//
+// Sequence (sizes from Reef's cost model, src/backend/costs.rs):
+//   setup            keys for G1 (Pallas) and G2 (Vesta): generated + pre-shifted on the GPU
+//   per folding step comm_T2 (|C2| Vesta) -> comm_W1 (|W1| Pallas) -> comm_T1 (|C1| Pallas)
+//                    -> comm_W2 (|W2| Vesta); each commitment feeds the next circuit's public
+//                    input, so the four MSMs are issued one after the other, result to host
+//   final SNARK      one more |C2| MSM, then for each curve an IPA over the padded key length:
+//                    log2 N rounds of { L, R cross MSMs (issued on two streams), generator fold }
+//   consistency      IPA of the Hyrax row length (prove_eval, commitment.rs:371/383)
+// Build: g++ -O2 -std=c++17 reef_replay.cpp -I../../../include -L../../_lib -lreef_msm -o reef_replay
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "reef_msm.h"
+
+#define CK(x)                                                                              \
+    do {                                                                                   \
+        reef_status s_ = (x);                                                              \
+        if (s_ != REEF_OK) { fprintf(stderr, "%s failed: %s\n", #x, reef_last_error()); exit(1); } \
+    } while (0)
+
+using clk = std::chrono::steady_clock;
+static double ms_since(clk::time_point t0) { return std::chrono::duration<double, std::milli>(clk::now() - t0).count(); }
+
+struct Shape {
+    const char *name;
+    size_t w1, c1, w2, c2;   // |W1|, |C1| (Pallas), |W2|, |C2| (Vesta)
+    int steps;
+    size_t hyrax_row;        // R = 2^(l - l/2): length of the consistency IPA (0 = merkle mode)
+};
+// BASELINE.json configs as sized in SURVEY.md 8 (predictions of costs.rs, not measurements)
+static const Shape SHAPES[] = {
+    {"cfg1_9B_ascii", 17000, 16700, 11400, 11376, 3, 4},
+    {"cfg3_1MiB_ascii_password", 26000, 26000, 11400, 11376, 3, 2048},
+    {"cfg4_16MiB_dna_hybrid_b32", 39000, 39000, 11400, 11376, 4, 8192},
+    {"cfg5_64MiB_utf8_merkle", 65000, 65000, 11400, 11376, 4, 0},
+};
+
+struct Curve {
+    int id;
+    reef_msm_ctx *key = nullptr;      // pre-shifted resident commitment key
+    reef_msm_ctx *ipa[2] = {nullptr, nullptr};  // plain contexts re-keyed every IPA round
+    reef_affine *d_gens = nullptr;    // device copy of the key for the IPA
+    size_t n = 0;
+};
+
+static size_t next_pow2(size_t x) { size_t p = 1; while (p < x) p <<= 1; return p; }
+
+static reef_fe *device_scalars(int curve, uint64_t seed, int kind, size_t n) {
+    reef_fe *p = (reef_fe *)reef_device_alloc(n * sizeof(reef_fe));
+    if (!p) { fprintf(stderr, "alloc: %s\n", reef_last_error()); exit(1); }
+    CK(reef_gen_scalars(curve, seed, kind, 0, n, true, p, REEF_DEVICE));
+    return p;
+}
+
+// One IPA: log2(n) rounds, two cross MSMs of n/2 points on two streams + the generator fold.
+static double run_ipa(Curve &c, size_t n, const reef_fe *d_scalars, int *rounds_out) {
+    auto t0 = clk::now();
+    reef_affine *cur = c.d_gens;
+    reef_affine *buf[2] = {(reef_affine *)reef_device_alloc(n / 2 * sizeof(reef_affine) + 64),
+                           (reef_affine *)reef_device_alloc(n / 2 * sizeof(reef_affine) + 64)};
+    reef_jacobian *dL = (reef_jacobian *)reef_device_alloc(2 * sizeof(reef_jacobian));
+    reef_jacobian L, R;
+    reef_fe w1 = {{0x1234567890abcdefULL, 0x0fedcba987654321ULL, 0x1111111122222222ULL, 0x0333333344444444ULL}};
+    reef_fe w2 = {{0x0badc0ffee0ddf00ULL, 0x0123456789abcdefULL, 0x5555555566666666ULL, 0x0777777788888888ULL}};
+    int rounds = 0, flip = 0;
+    for (size_t len = n; len > 1; len /= 2, ++rounds) {
+        const size_t half = len / 2;
+        CK(reef_msm_ctx_set_bases(c.ipa[0], cur + half, half, REEF_DEVICE));   // L = <a_lo, G_hi>
+        CK(reef_msm_ctx_set_bases(c.ipa[1], cur, half, REEF_DEVICE));          // R = <a_hi, G_lo>
+        // both cross terms in flight, then read them back (they feed the transcript)
+        CK(reef_msm(c.ipa[0], d_scalars, half, REEF_DEVICE, true, dL, REEF_DEVICE));
+        CK(reef_msm(c.ipa[1], d_scalars + half, half, REEF_DEVICE, true, dL + 1, REEF_DEVICE));
+        CK(reef_msm_ctx_sync(c.ipa[0]));
+        CK(reef_msm_ctx_sync(c.ipa[1]));
+        CK(reef_memcpy(&L, dL, sizeof L, REEF_HOST, REEF_DEVICE));
+        CK(reef_memcpy(&R, dL + 1, sizeof R, REEF_HOST, REEF_DEVICE));
+        CK(reef_fold(c.id, cur, half, REEF_DEVICE, &w1, &w2, buf[flip]));   // G' = w1*G_lo + w2*G_hi
+        cur = buf[flip];
+        flip ^= 1;
+    }
+    reef_device_free(buf[0]);
+    reef_device_free(buf[1]);
+    reef_device_free(dL);
+    if (rounds_out) *rounds_out = rounds;
+    return ms_since(t0);
+}
+
+int main(int argc, char **argv) {
+    const char *which = argc > 1 ? argv[1] : "cfg3_1MiB_ascii_password";
+    const Shape *sh = nullptr;
+    for (const Shape &s : SHAPES)
+        if (strstr(s.name, which)) sh = &s;
+    if (!sh) {
+        fprintf(stderr, "usage: reef_replay [cfg1|cfg3|cfg4|cfg5]\n");
+        return 2;
+    }
+    if (reef_device_count() < 1) { fprintf(stderr, "no GPU: %s\n", reef_last_error()); return 3; }
+
+    Curve cv[2];
+    cv[0].id = REEF_PALLAS; cv[0].n = next_pow2(sh->w1 > sh->c1 ? sh->w1 : sh->c1);
+    cv[1].id = REEF_VESTA;  cv[1].n = next_pow2(sh->w2 > sh->c2 ? sh->w2 : sh->c2);
+
+    auto t_setup = clk::now();
+    for (Curve &c : cv) {
+        c.d_gens = (reef_affine *)reef_device_alloc(c.n * sizeof(reef_affine));
+        CK(reef_gen_bases(c.id, 0xC0FFEE + c.id, 7, c.n, c.d_gens, REEF_DEVICE));
+        reef_msm_opts o = {};
+        o.bucket_groups = 1;  // commitment keys are fixed for the life of PublicParams: pre-shift once
+        o.device = -1;
+        CK(reef_msm_ctx_create(&c.key, c.id, c.d_gens, c.n, REEF_DEVICE, &o));
+        reef_msm_opts plain = {};
+        plain.device = -1;
+        for (auto &x : c.ipa) CK(reef_msm_ctx_create(&x, c.id, c.d_gens, c.n / 2, REEF_DEVICE, &plain));
+    }
+    const double setup_ms = ms_since(t_setup);
+
+    // witness-like scalars for W, uniform for the cross terms T
+    reef_fe *sW1 = device_scalars(REEF_PALLAS, 11, 1, cv[0].n), *sT1 = device_scalars(REEF_PALLAS, 12, 0, cv[0].n);
+    reef_fe *sW2 = device_scalars(REEF_VESTA, 13, 1, cv[1].n), *sT2 = device_scalars(REEF_VESTA, 14, 0, cv[1].n);
+
+    reef_jacobian out;
+    auto msm = [&](Curve &c, const reef_fe *s, size_t n) {
+        CK(reef_msm(c.key, s, n, REEF_DEVICE, true, &out, REEF_HOST));   // result to host: it feeds the next circuit
+    };
+    // warm-up (workspace allocation)
+    msm(cv[0], sW1, sh->w1); msm(cv[1], sW2, sh->w2);
+
+    auto t_steps = clk::now();
+    std::vector<double> step_ms;
+    for (int i = 0; i < sh->steps; ++i) {
+        auto ts = clk::now();
+        msm(cv[1], sT2, sh->c2);
+        msm(cv[0], sW1, sh->w1);
+        msm(cv[0], sT1, sh->c1);
+        msm(cv[1], sW2, sh->w2);
+        step_ms.push_back(ms_since(ts));
+    }
+    const double steps_ms = ms_since(t_steps);
+
+    auto t_final = clk::now();
+    msm(cv[1], sT2, sh->c2);  // last NIFS fold
+    int r1 = 0, r2 = 0, r3 = 0;
+    const double ipa1_ms = run_ipa(cv[0], cv[0].n, sT1, &r1);
+    const double ipa2_ms = run_ipa(cv[1], cv[1].n, sT2, &r2);
+    const double final_ms = ms_since(t_final);
+
+    double cons_ms = 0;
+    if (sh->hyrax_row >= 2) {
+        Curve hy;
+        hy.id = REEF_PALLAS; hy.n = sh->hyrax_row; hy.d_gens = cv[0].d_gens;  // prefix of the same key shape
+        for (int k = 0; k < 2; ++k) hy.ipa[k] = cv[0].ipa[k];
+        cons_ms = run_ipa(hy, hy.n, sT1, &r3);
+    }
+
+    const size_t pairs_step = sh->c2 + sh->w1 + sh->c1 + sh->w2;
+    printf("{\"replay\": \"%s\", \"note\": \"MSM work of reef --prove replayed through the C ABI; host-side proving work not included\", "
+           "\"key_pallas\": %zu, \"key_vesta\": %zu, \"steps\": %d, \"setup_ms\": %.3f, \"fold_steps_ms\": %.3f, \"ms_per_step\": %.3f, "
+           "\"pairs_per_step\": %zu, \"final_snark_ms\": %.3f, \"ipa_pallas_ms\": %.3f, \"ipa_pallas_rounds\": %d, \"ipa_vesta_ms\": %.3f, "
+           "\"ipa_vesta_rounds\": %d, \"consistency_ipa_ms\": %.3f, \"consistency_rounds\": %d, \"total_prove_msm_ms\": %.3f}\n",
+           sh->name, cv[0].n, cv[1].n, sh->steps, setup_ms, steps_ms, steps_ms / sh->steps, pairs_step, final_ms, ipa1_ms, r1, ipa2_ms, r2,
+           cons_ms, r3, steps_ms + final_ms + cons_ms);
+    for (Curve &c : cv) {
+        reef_msm_ctx_destroy(c.key);
+        for (auto &x : c.ipa) reef_msm_ctx_destroy(x);
+        reef_device_free(c.d_gens);
+    }
+    reef_device_free(sW1); reef_device_free(sT1); reef_device_free(sW2); reef_device_free(sT2);
+    return 0;
+}

@@ -106,6 +106,14 @@ class MsmContext:
         self._h = h
         self.n = n
 
+    def set_bases(self, bases: Buf, n: Optional[int] = None) -> None:
+        """Replace the key in place (IPA rounds: the generators change every round)."""
+        if n is None:
+            n = bases.shape[0]
+        loc, ptr = _loc_ptr(bases, 64 * n)
+        check(self._lib.reef_msm_ctx_set_bases(self._h, ptr, n, loc))
+        self.n = n
+
     def clone(self) -> "MsmContext":
         h = ctypes.c_void_p()
         check(self._lib.reef_msm_ctx_clone(ctypes.byref(h), self._h))
