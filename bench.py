@@ -187,6 +187,16 @@ def main():
         check = "dlog-ok" if ok else "MISMATCH"
 
     if rank == 0:
+        # HBM traffic of the dominant kernel: PMC counters need their own rocprofv3 passes (never
+        # combined with timing), so the value is read from the committed profile of this command
+        traffic = None
+        try:
+            prof = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
+            pc = prof["config"]
+            if (pc["curve"], pc["logn"], pc["window_bits"], pc["bucket_groups"]) == (a.curve, a.logn, plan["window_bits"], plan["bucket_groups"]):
+                traffic = prof["kernels"]["k_accum0<0>"]["hbm_bytes_per_launch"]
+        except (OSError, KeyError, ValueError):
+            pass
         pairs = n * a.gpus * a.steps
         value = pairs / elapsed
         achieved = BYTES_PER_PAIR * n / (acc_ms * 1e-3) / 1e9 if acc_ms > 0 else None
@@ -202,7 +212,8 @@ def main():
                        "exchange": "rccl all_gather of 96 B partials + on-device add" if a.gpus > 1 else "none",
                        "check": check, "msm_ms_stream": tot_ms},
             "roofline": {"bound": "hbm", "kernel": "k_accum0 (bucket accumulation)", "achieved": achieved, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": None,
+                         "unit": "GB/s", "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": traffic,
+                         "traffic_source": "profiles/r01_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes)" if traffic else None,
                          "kernel_ms": acc_ms, "algorithmic_bytes_per_launch": BYTES_PER_PAIR * n},
         }
         if a.gpus == 1 and not a.no_cpu_baseline:
