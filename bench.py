@@ -44,6 +44,8 @@ def parse():
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--cpu-seconds", type=float, default=12.0)
     p.add_argument("--no-check", action="store_true")
+    p.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                   help="nccl = RCCL over xGMI (default); gloo = host-staged gather (debug / boxes without RCCL), labelled as such")
     return p.parse_args()
 
 
@@ -102,11 +104,16 @@ def main():
     import torch.distributed as dist
     from reef_amd import msm
 
-    torch.cuda.set_device(local_rank)
-    msm.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    ndev = max(1, msm.device_count())
+    dev_index = local_rank % ndev          # one rank per GPU; (gloo debug runs may share a device)
+    torch.cuda.set_device(dev_index)
+    msm.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     if a.gpus > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        if a.backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group("gloo")
     n = 1 << a.logn
     k0, d = 0xABCDEF, 0x12345
     kind = 0 if a.scalars == "uniform" else 1
@@ -124,7 +131,13 @@ def main():
     parts = [torch.zeros(96, dtype=torch.uint8, device=dev) for _ in range(nctx)]
     gathered = [torch.zeros(96 * a.gpus, dtype=torch.uint8, device=dev) for _ in range(nctx)]
     results = [torch.zeros(96, dtype=torch.uint8, device=dev) for _ in range(nctx)]
-    ext = [torch.cuda.ExternalStream(c.stream, device=dev) for c in ctxs] if a.gpus > 1 else None
+    ext = None
+    if a.gpus > 1 and a.backend == "nccl":
+        try:                       # run the collective on the MSM's own HIP stream (no host sync per step)
+            ext = [torch.cuda.ExternalStream(c.stream, device=dev) for c in ctxs]
+        except Exception as e:     # older torch: fall back to a host sync before the collective
+            print(f"[bench] ExternalStream unavailable ({e}); syncing before each all_gather", file=sys.stderr)
+            ext = None
 
     def step(i):
         j = i % nctx
@@ -133,8 +146,20 @@ def main():
             c.msm(scalars, n, out=results[j].data_ptr())
         else:
             c.msm(scalars, n, out=parts[j].data_ptr())
-            with torch.cuda.stream(ext[j]):     # collective ordered after the MSM on the same stream
+            if ext is not None:
+                with torch.cuda.stream(ext[j]):     # collective ordered after the MSM on the same stream
+                    dist.all_gather_into_tensor(gathered[j], parts[j])
+            elif a.backend == "nccl":               # RCCL on torch's stream, ordered by a host sync
+                c.sync()
                 dist.all_gather_into_tensor(gathered[j], parts[j])
+                torch.cuda.current_stream().synchronize()
+            else:                                   # host-staged gather (gloo): 96 B per rank through host memory
+                c.sync()
+                host = parts[j].cpu()
+                outs = [torch.empty_like(host) for _ in range(a.gpus)]
+                dist.all_gather(outs, host)
+                gathered[j].copy_(torch.cat(outs))
+                torch.cuda.synchronize()
             c.sum_points(gathered[j].data_ptr(), a.gpus, results[j].data_ptr())
 
     def sync_all():
@@ -159,7 +184,7 @@ def main():
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     if a.gpus > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev if a.backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
@@ -176,11 +201,12 @@ def main():
         got_local = msm.compress(a.curve, (parts if a.gpus > 1 else results)[(a.steps - 1) % nctx].cpu().numpy().view(np.uint64))
         ok = got_local == local
         if a.gpus > 1:
-            flag = torch.tensor([1 if ok else 0], device=dev)
+            cdev = dev if a.backend == "nccl" else "cpu"
+            flag = torch.tensor([1 if ok else 0], device=cdev)
             dist.all_reduce(flag, op=dist.ReduceOp.MIN)
             ok = bool(flag.item())
             # all ranks must hold the same combined point
-            comb = results[(a.steps - 1) % nctx].clone()
+            comb = results[(a.steps - 1) % nctx].clone().to(cdev)
             ref = comb.clone()
             dist.broadcast(ref, 0)
             ok = ok and bool((ref == comb).all().item())
@@ -209,7 +235,8 @@ def main():
                        "points_per_gpu": n, "total_points": n * a.gpus, "window_bits": plan["window_bits"],
                        "windows": plan["windows"], "bucket_groups": plan["bucket_groups"], "tables": plan["tables"],
                        "streams": nctx, "sharding": "points" if a.gpus > 1 else "none",
-                       "exchange": "rccl all_gather of 96 B partials + on-device add" if a.gpus > 1 else "none",
+                       "exchange": ("none" if a.gpus == 1 else "rccl all_gather of 96 B partials + on-device add" if a.backend == "nccl"
+                                    else "HOST-STAGED gloo all_gather of 96 B partials (debug fallback, not RCCL) + on-device add"),
                        "check": check, "msm_ms_stream": tot_ms},
             "roofline": {"bound": "hbm", "kernel": "k_accum0 (bucket accumulation)", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": traffic,
