@@ -317,3 +317,25 @@ def test_normalize_matches_oracle(gpu_lib, cref):
         aff, comp = msm.normalize(cid, jac, affine=True, compressed=True)
         assert (aff == cref.to_affine(cid, jac)).all()
         assert comp.tobytes() == cref.compress(cid, jac)
+
+
+@pytest.mark.parametrize("rows,row_len,bound", [(1024, 2048, 131), (512, 4096, 7)])
+def test_rows_baseline_size_dlog_property(rows, row_len, bound, gpu_lib):
+    """HyraxPC::commit at BASELINE.json configs[2] size (1 MiB ASCII document = 1024 rows x 2048
+    symbols): bases in arithmetic progression, so row r must be (sum_j Z[r,j]*(k0 + j*d))*G."""
+    from reef_amd import msm
+    C = CURVES["pallas"]
+    k0, d = 1234567, 89
+    bases = msm.gen_bases("pallas", k0, d, row_len, device=True)
+    sc = msm.gen_scalars("pallas", 0xD0C, rows * row_len, kind=2, small_bound=bound, device=True)
+    out = msm.DeviceBuffer(96 * rows)
+    with msm.MsmContext("pallas", bases, row_len) as ctx:
+        ctx.msm_rows(sc, rows, row_len, out=out)
+        ctx.sync()
+    comp = msm.compress("pallas", out.to_host((rows, 12)))
+    canon = msm.gen_scalars("pallas", 0xD0C, rows * row_len, kind=2, small_bound=bound, mont=False)[:, 0].astype(object)
+    canon = canon.reshape(rows, row_len)
+    w = k0 + np.arange(row_len, dtype=object) * d
+    for r in list(range(0, rows, 97)) + [rows - 1]:
+        acc = int((canon[r] * w).sum()) % C.order
+        assert comp[32 * r:32 * r + 32] == C.compress(C.mul(acc, C.gen)), r
