@@ -18,6 +18,13 @@
 #pragma once
 #include "field.h"
 
+// wave-wide "any lane" test on the device (skips rarely-needed selects for the whole wave)
+#if defined(__HIP_DEVICE_COMPILE__)
+#define REEF_ANY(x) __any(x)
+#else
+#define REEF_ANY(x) (x)
+#endif
+
 namespace reef {
 
 // in-register forms (29-bit limbs, internal Montgomery form)
@@ -111,10 +118,8 @@ template <int C> REEF_HD xyzz xyzz_dbl(const xyzz &p) {
 template <int C> REEF_HD xyzz xyzz_madd_flag(const xyzz &a, bool a_known_empty, const affine &p) {
     const bool a_inf = a_known_empty || xyzz_is_inf<C>(a);
     const bool p_inf = affine_is_inf(p);
-    const fe u2 = fe_mul<C>(p.x, a.zz);                       // < 1.02
-    const fe s2 = fe_mul<C>(p.y, a.zzz);                      // < 1.04
-    const fe pp_ = fe_sub<C, 8>(u2, a.x);                     // < 9.02   (X1 < 8)
-    const fe rr = fe_sub<C, 4>(s2, a.y);                      // < 5.04   (Y1 < 4)
+    const fe pp_ = fe_mul_sub<C, 8>(p.x, a.zz, a.x);          // U2 - X1: 1.02 + 8   -> < 9.02   (X1 < 8)
+    const fe rr = fe_mul_sub<C, 4>(p.y, a.zzz, a.y);          // S2 - Y1: 1.04 + 4   -> < 5.04   (Y1 < 4)
     xyzz r;
     if (__builtin_expect(fe_is_zero<C>(pp_) && fe_is_zero<C>(rr) && !a_inf && !p_inf, 0)) {
         r = xyzz_dbl_affine<C>(p);
@@ -122,17 +127,22 @@ template <int C> REEF_HD xyzz xyzz_madd_flag(const xyzz &a, bool a_known_empty, 
         const fe pp = fe_sqr<C>(pp_);                         // 81.4/128    -> < 1.64
         const fe ppp = fe_mul<C>(pp_, pp);                    // 14.8/128    -> < 1.12
         const fe q = fe_mul<C>(a.x, pp);                      // 13.1/128    -> < 1.11
-        const fe t = fe_add<C>(ppp, fe_dbl<C>(q));            // < 3.34
-        r.x = fe_sub<C, 4>(fe_sqr<C>(rr), t);                 // 1.2 + 4     -> < 5.2   (t < 4)
-        r.y = fe_sub<C, 2>(fe_mul<C>(rr, fe_sub<C, 8>(q, r.x)),  // 5.04*9.11 = 46 -> < 1.36
-                           fe_mul<C>(a.y, ppp));              // 4.5/128     -> < 1.04 < 2 ; y3 < 3.4
+        fe t;                                                 // PPP + 2Q < 3.34, left un-normalised
+#pragma unroll
+        for (int i = 0; i < 9; ++i) t.l[i] = ppp.l[i] + 2u * q.l[i];   // limbs < 3 * 2^29 < 2^31 - 4
+        REEF_SET_BOUND(t, REEF_GET_BOUND(ppp) + 2.0 * REEF_GET_BOUND(q));
+        r.x = fe_sqr_sub<C, 4>(rr, t);                        // 1.2 + 4     -> < 5.2   (t < 4)
+        const fe m2 = fe_mul<C>(a.y, ppp);                    // 4.5/128     -> < 1.04
+        r.y = fe_mul_sub<C, 2>(rr, fe_sub<C, 8>(q, r.x), m2); // 5.04*9.11 = 46 -> 1.36 + 2 -> < 3.4
         r.zz = fe_mul<C>(a.zz, pp);                           // < 1.03
         r.zzz = fe_mul<C>(a.zzz, ppp);                        // < 1.02
     }
-    xyzz from_p;
-    from_p.x = p.x; from_p.y = p.y; from_p.zz = fe_one<C>(); from_p.zzz = from_p.zz;
-    r = xyzz_select(a_inf, from_p, r);  // O + P = P
-    r = xyzz_select(p_inf, a, r);       // acc + O = acc
+    if (REEF_ANY(a_inf)) {                                    // O + P = P
+        xyzz from_p;
+        from_p.x = p.x; from_p.y = p.y; from_p.zz = fe_one<C>(); from_p.zzz = from_p.zz;
+        r = xyzz_select(a_inf, from_p, r);
+    }
+    if (REEF_ANY(p_inf)) r = xyzz_select(p_inf, a, r);        // acc + O = acc
     return r;
 }
 

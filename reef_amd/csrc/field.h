@@ -166,6 +166,15 @@ template <int F, int K> REEF_HD fe fe_sub(const fe &a, const fe &b) {
 }
 template <int F, int K> REEF_HD fe fe_neg(const fe &a) { return fe_sub<F, K>(fe_zero(), a); }
 
+#if defined(__HIP_DEVICE_COMPILE__)
+__device__ __forceinline__ void mad_acc_1(u64 &acc, u32 a) {  // acc += a (one v_mad_u64_u32 with the inline constant 1)
+    u64 sink;
+    asm("v_mad_u64_u32 %0, %1, %2, 1, %0" : "+v"(acc), "=&s"(sink) : "v"(a));
+}
+#else
+REEF_HD void mad_acc_1(u64 &acc, u32 a) { acc += a; }
+#endif
+
 #if !defined(__HIP_DEVICE_COMPILE__)
 // Host forms of the row operations (the gfx950 forms are whole rows of v_mad_u64_u32 in one
 // asm statement each: field_mad_gfx950.h).
@@ -260,6 +269,34 @@ template <int F> REEF_HD fe fe_mul(const fe &a, const fe &b) {
     return r;
 }
 
+// a*b + K*M - c in one pass: the limbs of (bias - c) are dropped into the column accumulators
+// before the final carry, so the subtraction costs 18 instructions and no extra normalisation.
+// Requires c < K*M with limbs < 2^31 - 4; result value < (2 + K)*M, exact 29-bit limbs.
+template <int F, int K> REEF_HD fe fe_mul_sub(const fe &a, const fe &b, const fe &c) {
+#if defined(REEF_BOUNDS)
+    if (a.bound * b.bound >= 128.0) REEF_BOUND_FAIL("fe_mul_sub: (A/M)(B/M) >= 128");
+    if (c.bound > (double)K * (1.0 - 1e-5)) REEF_BOUND_FAIL("fe_mul_sub: subtrahend bound exceeds the bias");
+    for (int i = 0; i < 8; ++i)
+        if (a.l[i] > LIMB_MASK + 8 || b.l[i] > LIMB_MASK + 8) REEF_BOUND_FAIL("fe_mul_sub: operand not normalised");
+    for (int i = 0; i < 9; ++i)
+        if (c.l[i] > fe_bias<F, K>()[i]) REEF_BOUND_FAIL("fe_mul_sub: subtrahend limb exceeds the bias limb");
+#endif
+    u64 t[10];
+    t[9] = 0;
+    mad_row_new(t, a.l, b.l[0]);
+    mont_round<F>(t);
+#pragma unroll
+    for (int i = 1; i < 9; ++i) {
+        mad_row_acc(t, a.l, b.l[i]);
+        mont_round<F>(t);
+    }
+#pragma unroll
+    for (int i = 0; i < 9; ++i) mad_acc_1(t[i], fe_bias<F, K>()[i] - c.l[i]);
+    fe r = mont_finish<F>(t);
+    REEF_SET_BOUND(r, 1.0 + REEF_GET_BOUND(a) * REEF_GET_BOUND(b) / 128.0 + K);
+    return r;
+}
+
 // Montgomery square: 45 instead of 81 partial products (a_i*a_j, i < j, taken once with 2*a_j;
 // row i holds columns i..i+8 in t[0..8], so a_i*a_j lands in slot j).
 template <int F> REEF_HD fe fe_sqr(const fe &a) {
@@ -284,6 +321,36 @@ template <int F> REEF_HD fe fe_sqr(const fe &a) {
     sqr_row<8>(t, a.l, a2); mont_round<F>(t);
     fe r = mont_finish<F>(t);
     REEF_SET_BOUND(r, 1.0 + REEF_GET_BOUND(a) * REEF_GET_BOUND(a) / 128.0);
+    return r;
+}
+
+template <int F, int K> REEF_HD fe fe_sqr_sub(const fe &a, const fe &c) {
+#if defined(REEF_BOUNDS)
+    if (a.bound * a.bound >= 128.0) REEF_BOUND_FAIL("fe_sqr_sub: (A/M)^2 >= 128");
+    if (c.bound > (double)K * (1.0 - 1e-5)) REEF_BOUND_FAIL("fe_sqr_sub: subtrahend bound exceeds the bias");
+    for (int i = 0; i < 8; ++i)
+        if (a.l[i] > LIMB_MASK + 8) REEF_BOUND_FAIL("fe_sqr_sub: operand not normalised");
+    for (int i = 0; i < 9; ++i)
+        if (c.l[i] > fe_bias<F, K>()[i]) REEF_BOUND_FAIL("fe_sqr_sub: subtrahend limb exceeds the bias limb");
+#endif
+    u32 a2[9];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) a2[i] = a.l[i] << 1;
+    u64 t[10];
+    t[9] = 0;
+    sqr_row<0>(t, a.l, a2); mont_round<F>(t);
+    sqr_row<1>(t, a.l, a2); mont_round<F>(t);
+    sqr_row<2>(t, a.l, a2); mont_round<F>(t);
+    sqr_row<3>(t, a.l, a2); mont_round<F>(t);
+    sqr_row<4>(t, a.l, a2); mont_round<F>(t);
+    sqr_row<5>(t, a.l, a2); mont_round<F>(t);
+    sqr_row<6>(t, a.l, a2); mont_round<F>(t);
+    sqr_row<7>(t, a.l, a2); mont_round<F>(t);
+    sqr_row<8>(t, a.l, a2); mont_round<F>(t);
+#pragma unroll
+    for (int i = 0; i < 9; ++i) mad_acc_1(t[i], fe_bias<F, K>()[i] - c.l[i]);
+    fe r = mont_finish<F>(t);
+    REEF_SET_BOUND(r, 1.0 + REEF_GET_BOUND(a) * REEF_GET_BOUND(a) / 128.0 + K);
     return r;
 }
 
