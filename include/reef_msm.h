@@ -141,6 +141,37 @@ reef_status reef_gen_scalars(int curve, uint64_t seed, int kind, uint64_t small_
                              bool to_mont, reef_fe *out, int loc);
 
 /* ---------------------------------------------------------------------------------------------
+ * (3b) Row N2 ("next" in SURVEY.md 8f): the host sum-check of nlookup witness generation as
+ * vector kernels over the scalar field of `curve` (Reef: REEF_PALLAS, i.e. Fq, the CirC modulus of
+ * src/backend/r1cs_helper.rs:37-38).  All values cross the ABI as canonical integers, 32 bytes
+ * little-endian -- what the reference's rug::Integer tables hold -- NOT in Montgomery form.
+ * Replaces, per folding step (src/backend/r1cs.rs:2318-2385):
+ *   gen_eq_table              r1cs_helper.rs:508-544  -> reef_sc_gen_eq_table
+ *   linear_mle_product        r1cs_helper.rs:441-506  -> reef_sc_round_coeffs (sums, :455-476), then
+ *                                                        reef_sc_fold (both tables, :491-503) with the
+ *                                                        Poseidon challenge the host derived (:478-489)
+ *   prover_mle_partial_eval(table, sc_rs)  :551-634   -> after the last round the folded table holds
+ *                                                        the value in entry 0: reef_sc_read(ctx, 0, 1, ..)
+ * ------------------------------------------------------------------------------------------- */
+typedef struct reef_sc_ctx reef_sc_ctx;
+/* Two resident tables (T = lookup table or document, EQ) of table_len = 2^ell entries each. */
+reef_status reef_sc_create(reef_sc_ctx **out, int curve, size_t table_len);
+void reef_sc_destroy(reef_sc_ctx *ctx);
+/* which: 0 = T, 1 = EQ.  n <= table_len values; the rest is zero-padded (r1cs.rs:2323-2330). */
+reef_status reef_sc_set_table(reef_sc_ctx *ctx, int which, const reef_fe *values, size_t n, int loc);
+/* EQ[i] = sum_{k: qs[k] = i} rs[k] + rs[nq] * prod_j (bit_j(i) ? last_q[j] : 1 - last_q[j]);
+ * rs has nq + 1 entries, last_q has ell entries (host arrays). */
+reef_status reef_sc_gen_eq_table(reef_sc_ctx *ctx, const reef_fe *rs, const uint32_t *qs, size_t nq,
+                                 const reef_fe *last_q, size_t ell);
+/* Round with pow = 2^(ell - i): out = { xsq, x, con } (host). */
+reef_status reef_sc_round_coeffs(reef_sc_ctx *ctx, size_t pow, reef_fe out[3]);
+/* X[b] = X[b]*(1 - r) + X[b + pow]*r for b < pow, both tables, in place (asynchronous). */
+reef_status reef_sc_fold(reef_sc_ctx *ctx, size_t pow, const reef_fe *r);
+/* Read back the first `count` entries of a table as canonical integers (host). */
+reef_status reef_sc_read(reef_sc_ctx *ctx, int which, size_t count, reef_fe *out);
+reef_status reef_sc_sync(reef_sc_ctx *ctx);
+
+/* ---------------------------------------------------------------------------------------------
  * (4) Runtime plumbing.
  * ------------------------------------------------------------------------------------------- */
 int reef_device_count(void);

@@ -570,3 +570,44 @@ void pasta_ref_row_msm(int curve, const u64 *bases, const u64 *h, const u64 *sca
     free(jobs);
     free(tids);
 }
+
+/* ---- row N2: sum-check round on the CPU (restates linear_mle_product, r1cs_helper.rs:441-506,
+ * with the challenge supplied by the caller).  Tables hold canonical integers; they are moved to
+ * Montgomery form once (pasta_ref_sc_to_mont) so that a round costs what the reference's
+ * rug::Integer multiply + rem_floor costs: one modular product per term. */
+void pasta_ref_sc_to_mont(int field, u64 *table, size_t n) {
+    const field_t *F = field_of(field);
+    for (size_t i = 0; i < n; ++i) fe_to_mont(F, (fe *)(table + 4 * i), (const fe *)(table + 4 * i));
+}
+void pasta_ref_sc_from_mont(int field, u64 *table, size_t n) {
+    const field_t *F = field_of(field);
+    for (size_t i = 0; i < n; ++i) fe_from_mont(F, (fe *)(table + 4 * i), (const fe *)(table + 4 * i));
+}
+/* out3 = (xsq, x, con) canonical; then both tables are folded with r (canonical). */
+void pasta_ref_sc_round(int field, u64 *T, u64 *E, size_t pow, const u64 *r_canon, u64 *out3) {
+    const field_t *F = field_of(field);
+    fe xsq, x, con, r, t;
+    memset(&xsq, 0, 32); memset(&x, 0, 32); memset(&con, 0, 32);
+    for (size_t b = 0; b < pow; ++b) {
+        const fe *t0 = (const fe *)(T + 4 * b), *t1 = (const fe *)(T + 4 * (b + pow));
+        const fe *e0 = (const fe *)(E + 4 * b), *e1 = (const fe *)(E + 4 * (b + pow));
+        fe ts, es;
+        fe_sub(F, &ts, t1, t0);
+        fe_sub(F, &es, e1, e0);
+        fe_mul(F, &t, &ts, &es); fe_add(F, &xsq, &xsq, &t);
+        fe_mul(F, &t, &es, t0);  fe_add(F, &x, &x, &t);
+        fe_mul(F, &t, &ts, e0);  fe_add(F, &x, &x, &t);
+        fe_mul(F, &t, t0, e0);   fe_add(F, &con, &con, &t);
+    }
+    fe_from_mont(F, (fe *)out3, &xsq);
+    fe_from_mont(F, (fe *)(out3 + 4), &x);
+    fe_from_mont(F, (fe *)(out3 + 8), &con);
+    fe_to_mont(F, &r, (const fe *)r_canon);
+    for (size_t b = 0; b < pow; ++b) {
+        fe *t0 = (fe *)(T + 4 * b), *e0 = (fe *)(E + 4 * b);
+        const fe *t1 = (const fe *)(T + 4 * (b + pow)), *e1 = (const fe *)(E + 4 * (b + pow));
+        fe d;
+        fe_sub(F, &d, t1, t0); fe_mul(F, &d, &d, &r); fe_add(F, t0, t0, &d);
+        fe_sub(F, &d, e1, e0); fe_mul(F, &d, &d, &r); fe_add(F, e0, e0, &d);
+    }
+}

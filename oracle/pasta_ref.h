@@ -73,6 +73,13 @@ void pasta_ref_row_msm(int curve, const uint64_t *bases_affine, const uint64_t *
                        const uint64_t *scalars, const uint64_t *blinds, size_t rows,
                        size_t row_len, int scalars_are_mont, int threads, uint64_t *out_jacobian);
 
+/* Row N2 (sum-check of nlookup witness generation, r1cs_helper.rs:441-506): tables of canonical
+ * integers are moved to Montgomery form once, then each round returns (xsq, x, con) and folds both
+ * tables with the caller's challenge. */
+void pasta_ref_sc_to_mont(int field, uint64_t *table, size_t n);
+void pasta_ref_sc_from_mont(int field, uint64_t *table, size_t n);
+void pasta_ref_sc_round(int field, uint64_t *T, uint64_t *E, size_t pow, const uint64_t *r_canon, uint64_t *out3);
+
 #ifdef __cplusplus
 }
 #endif

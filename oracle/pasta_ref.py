@@ -46,8 +46,9 @@ def lib() -> ctypes.CDLL:
             getattr(_lib, "pasta_ref_" + name).argtypes = [i32, vp, vp]
         _lib.pasta_ref_fold.argtypes = [i32, vp, sz, vp, vp, vp]
         _lib.pasta_ref_row_msm.argtypes = [i32, vp, vp, vp, vp, sz, sz, i32, i32, vp]
-        for f in dir(_lib):
-            pass
+        _lib.pasta_ref_sc_to_mont.argtypes = [i32, vp, sz]
+        _lib.pasta_ref_sc_from_mont.argtypes = [i32, vp, sz]
+        _lib.pasta_ref_sc_round.argtypes = [i32, vp, vp, sz, vp, vp]
     return _lib
 
 
@@ -134,3 +135,19 @@ def int_to_limbs(v: int) -> np.ndarray:
 
 def limbs_to_int(a) -> int:
     return sum(int(x) << (64 * i) for i, x in enumerate(np.asarray(a).reshape(-1)[:4]))
+
+
+def sc_round(field: int, T: np.ndarray, E: np.ndarray, pow_: int, r: int) -> tuple:
+    """One sum-check round on Montgomery-form tables (see sc_to_mont); returns (xsq, x, con)."""
+    out = np.zeros((3, 4), dtype=np.uint64)
+    rr = int_to_limbs(r)
+    lib().pasta_ref_sc_round(field, _p(T), _p(E), pow_, _p(rr), _p(out))
+    return tuple(limbs_to_int(out[i]) for i in range(3))
+
+
+def sc_to_mont(field: int, table: np.ndarray) -> None:
+    lib().pasta_ref_sc_to_mont(field, _p(table), table.shape[0])
+
+
+def sc_from_mont(field: int, table: np.ndarray) -> None:
+    lib().pasta_ref_sc_from_mont(field, _p(table), table.shape[0])

@@ -84,6 +84,14 @@ def load() -> ctypes.CDLL:
         "reef_msm_ctx_plan": (c_int, [vp, POINTER(c_uint32), POINTER(c_uint32), POINTER(c_uint32), POINTER(c_uint32)]),
         "reef_msm_plan_for": (c_int, [c_size_t, c_uint32, c_uint32, POINTER(c_uint32), POINTER(c_uint32), POINTER(c_uint32),
                                       POINTER(c_uint32)]),
+        "reef_sc_create": (c_int, [POINTER(vp), c_int, c_size_t]),
+        "reef_sc_destroy": (None, [vp]),
+        "reef_sc_set_table": (c_int, [vp, c_int, vp, c_size_t, c_int]),
+        "reef_sc_gen_eq_table": (c_int, [vp, vp, vp, c_size_t, vp, c_size_t]),
+        "reef_sc_round_coeffs": (c_int, [vp, c_size_t, vp]),
+        "reef_sc_fold": (c_int, [vp, c_size_t, vp]),
+        "reef_sc_read": (c_int, [vp, c_int, c_size_t, vp]),
+        "reef_sc_sync": (c_int, [vp]),
         "reef_test_field_op": (c_int, [c_int, c_int, vp, vp, vp, c_size_t]),
         "reef_test_ec_op": (c_int, [c_int, c_int, vp, vp, vp, vp, c_size_t]),
         "reef_bench_fmul": (c_int, [c_int, c_uint32, POINTER(c_double)]),

@@ -204,6 +204,50 @@ reef_status reef_bench_fmul(int field, uint32_t iters, double *products_per_s) {
     return v->bench_fmul(iters, products_per_s);
 }
 
+// ---- row N2: sum-check vector kernels
+struct reef_sc_ctx {
+    int curve;
+    void *impl;
+};
+reef_status reef_sc_create(reef_sc_ctx **out, int curve, size_t table_len) {
+    if (!out) { set_error("null argument"); return REEF_ERR_ARG; }
+    STATELESS_PROLOGUE(curve);
+    void *impl = nullptr;
+    REEF_TRY(v->sc_create(&impl, table_len));
+    *out = new reef_sc_ctx{curve, impl};
+    return REEF_OK;
+}
+void reef_sc_destroy(reef_sc_ctx *ctx) {
+    if (!ctx) return;
+    vt(ctx->curve)->sc_destroy(ctx->impl);
+    delete ctx;
+}
+#define SC_CHECK(ctx) if (!(ctx)) { set_error("null argument"); return REEF_ERR_ARG; }
+reef_status reef_sc_set_table(reef_sc_ctx *ctx, int which, const reef_fe *values, size_t n, int loc) {
+    SC_CHECK(ctx);
+    return vt(ctx->curve)->sc_set(ctx->impl, which, values, n, loc);
+}
+reef_status reef_sc_gen_eq_table(reef_sc_ctx *ctx, const reef_fe *rs, const uint32_t *qs, size_t nq, const reef_fe *last_q, size_t ell) {
+    SC_CHECK(ctx);
+    return vt(ctx->curve)->sc_gen_eq(ctx->impl, rs, qs, nq, last_q, ell);
+}
+reef_status reef_sc_round_coeffs(reef_sc_ctx *ctx, size_t pow, reef_fe out[3]) {
+    SC_CHECK(ctx);
+    return vt(ctx->curve)->sc_coeffs(ctx->impl, pow, out);
+}
+reef_status reef_sc_fold(reef_sc_ctx *ctx, size_t pow, const reef_fe *r) {
+    SC_CHECK(ctx);
+    return vt(ctx->curve)->sc_fold(ctx->impl, pow, r);
+}
+reef_status reef_sc_read(reef_sc_ctx *ctx, int which, size_t count, reef_fe *out) {
+    SC_CHECK(ctx);
+    return vt(ctx->curve)->sc_read(ctx->impl, which, count, out);
+}
+reef_status reef_sc_sync(reef_sc_ctx *ctx) {
+    SC_CHECK(ctx);
+    return vt(ctx->curve)->sc_sync(ctx->impl);
+}
+
 // ---- pasta-msm drop-in symbols: stateless, abort on failure (the Rust side panics on error).
 // A per-thread context is kept so that repeated calls reuse the workspace; the bases are
 // re-uploaded on every call, as the reference semantics (nothing retained) require.

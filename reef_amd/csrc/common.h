@@ -68,6 +68,15 @@ struct CurveVTable {
     reef_status (*test_field_op)(int op, const reef_fe *a, const reef_fe *b, reef_fe *out, size_t n);  // coordinate field
     reef_status (*test_ec_op)(int op, const reef_affine *p, const reef_affine *q, const reef_fe *k, reef_jacobian *out, size_t n);
     reef_status (*bench_fmul)(uint32_t iters, double *per_s);
+    // row N2: sum-check vector kernels over the curve's scalar field
+    reef_status (*sc_create)(void **impl, size_t len);
+    void (*sc_destroy)(void *impl);
+    reef_status (*sc_set)(void *impl, int which, const reef_fe *vals, size_t n, int loc);
+    reef_status (*sc_read)(void *impl, int which, size_t count, reef_fe *out_host);
+    reef_status (*sc_coeffs)(void *impl, size_t pow, reef_fe *out3_host);
+    reef_status (*sc_fold)(void *impl, size_t pow, const reef_fe *r);
+    reef_status (*sc_gen_eq)(void *impl, const reef_fe *rs, const uint32_t *qs, size_t nq, const reef_fe *last_q, size_t ell);
+    reef_status (*sc_sync)(void *impl);
     reef_status (*plan_for)(size_t n, uint32_t c_opt, uint32_t g_opt, uint32_t *c, uint32_t *w, uint32_t *g, uint32_t *t);
 };
 

@@ -1,6 +1,7 @@
 // Pallas instantiation of the MSM engine (coordinates in Fp, scalars in Fq).
 #define REEF_CURVE 0
 #include "msm_kernels.inc"
+#include "sumcheck_kernels.inc"
 #include "engine.inc"
 namespace reef {
 const CurveVTable *pallas_vtable() {

@@ -1,6 +1,7 @@
 // Vesta instantiation of the MSM engine (coordinates in Fq, scalars in Fp).
 #define REEF_CURVE 1
 #include "msm_kernels.inc"
+#include "sumcheck_kernels.inc"
 #include "engine.inc"
 namespace reef {
 const CurveVTable *vesta_vtable() {

@@ -1,0 +1,102 @@
+"""Row N2: the sum-check vector kernels (through the C ABI) against oracle/sumcheck_oracle.py,
+which is pinned to the reference's own tests (tests/test_sumcheck_oracle.py).  Bit-exact:
+every value is a canonical integer mod q."""
+import numpy as np
+import pytest
+
+from oracle.pasta_oracle import SplitMix64, uniform_scalar
+from oracle.sumcheck_oracle import Q, gen_eq_table, linear_mle_coeffs, linear_mle_fold, verifier_mle_eval
+
+pytestmark = pytest.mark.gpu
+
+
+def test_reference_test_vectors_on_gpu(gpu_lib):
+    """mle_linear_basic (r1cs.rs:2411-2515) with the reference's inputs, run on the GPU."""
+    from reef_amd.sumcheck import SumCheck
+    evals = [2, 3, 5, 7, 9, 13, 17, 19]
+    qs, last_q, claims = [2, 1, 7], [2, 3, 5], [3, 9, 27, 81]
+    eq_ref = gen_eq_table(claims, qs, list(reversed(last_q)))
+    with SumCheck("pallas", 3) as sc:
+        sc.set_table(0, evals)
+        sc.gen_eq_table(claims, qs, list(reversed(last_q)))
+        assert sc.read(1, 8) == eq_ref
+        t, e = list(evals), list(eq_ref)
+        claim = sum(a * b for a, b in zip(t, e)) % Q
+        rs = [5, Q - 3, 0x1234567890ABCDEF]
+        for i in range(1, 4):
+            got = sc.round_coeffs(i)
+            assert got == linear_mle_coeffs(t, e, 3, i)
+            xsq, x, con = got
+            assert claim == (2 * con + x + xsq) % Q              # the reference's sanity assertion
+            sc.fold(i, rs[i - 1])
+            linear_mle_fold(t, e, 3, i, rs[i - 1])
+            claim = (xsq * rs[i - 1] ** 2 + x * rs[i - 1] + con) % Q
+            assert sc.read(0, 1 << (3 - i)) == t[: 1 << (3 - i)]
+            assert sc.read(1, 1 << (3 - i)) == e[: 1 << (3 - i)]
+        # prover_mle_partial_eval(table, sc_rs) == the folded table (r1cs.rs:2379-2385)
+        assert sc.read(0, 1)[0] == verifier_mle_eval(evals, rs)
+
+
+@pytest.mark.parametrize("curve,ell,n_t", [("pallas", 10, 1000), ("pallas", 14, 1 << 14), ("vesta", 9, 300)])
+def test_full_sumcheck_vs_oracle(curve, ell, n_t, gpu_lib):
+    """Random full-width table (zero-padded like the nldoc case), random eq inputs, every round."""
+    from reef_amd.sumcheck import SumCheck
+    from oracle.pasta_oracle import CURVES
+    q = CURVES[curve].order
+    rng = SplitMix64(ell * 1000 + n_t)
+    table = [uniform_scalar(rng, q) for _ in range(n_t)]
+    nq = 5
+    qs = [rng.next() % (1 << ell) for _ in range(nq)]
+    qs[1] = qs[0]                                                # repeated lookup index
+    claim_r = uniform_scalar(rng, q)
+    rs = [pow(claim_r, k + 1, q) for k in range(nq + 1)]
+    last_q = [uniform_scalar(rng, q) for _ in range(ell)]
+    t = table + [0] * ((1 << ell) - n_t)
+    e = gen_eq_table(rs, qs, last_q, q)
+    with SumCheck(curve, ell) as sc:
+        sc.set_table(0, table)
+        sc.gen_eq_table(rs, qs, last_q)
+        assert sc.read(1, 1 << ell) == e
+        challenges = []
+        for i in range(1, ell + 1):
+            assert sc.round_coeffs(i) == linear_mle_coeffs(t, e, ell, i, q), i
+            r = uniform_scalar(rng, q)
+            challenges.append(r)
+            sc.fold(i, r)
+            linear_mle_fold(t, e, ell, i, r, q)
+        assert sc.read(0, 1) == [t[0]] and sc.read(1, 1) == [e[0]]
+    if ell <= 10:
+        assert t[0] == verifier_mle_eval(table + [0] * ((1 << ell) - n_t), challenges, q)
+
+
+def test_baseline_size_identity(gpu_lib):
+    """cfg3 size (1 MiB document -> 2^21 entries): the sum-check identity claim = g(0) + g(1)
+    round after round, and small-symbol tables (document symbols < 131)."""
+    from reef_amd.sumcheck import SumCheck
+    from reef_amd import msm
+    ell = 21
+    n = 1 << ell
+    doc = msm.gen_scalars("pallas", 0xD0C, n, kind=2, small_bound=131, mont=False)       # canonical integers
+    eqv = msm.gen_scalars("pallas", 0xE9, n, kind=0, mont=False)
+    with SumCheck("pallas", ell) as sc:
+        sc.set_table(0, doc)
+        sc.set_table(1, eqv)
+        rng = SplitMix64(99)
+        xsq, x, con = sc.round_coeffs(1)
+        # independent O(n) check of the first round's constant term with numpy object ints
+        d = [doc[:, j].astype(object) for j in range(4)]
+        e = [eqv[:, j].astype(object) for j in range(4)]
+        half = n // 2
+        dv = d[0][:half]                                        # symbols < 131 live in limb 0
+        ev = sum(e[j][:half] * (1 << (64 * j)) for j in range(4))
+        assert con == int((dv * ev).sum()) % Q
+        claim = (2 * con + x + xsq) % Q
+        for i in range(1, ell + 1):
+            if i > 1:
+                xsq, x, con = sc.round_coeffs(i)
+                assert claim == (2 * con + x + xsq) % Q, i
+            r = uniform_scalar(rng, Q)
+            sc.fold(i, r)
+            claim = (xsq * r * r + x * r + con) % Q
+        t0, e0 = sc.read(0, 1)[0], sc.read(1, 1)[0]
+        assert claim == t0 * e0 % Q                             # final claim = T~(r) * EQ~(r)

@@ -1,0 +1,50 @@
+#!/usr/bin/env python3
+"""Time the sum-check vector kernels (row N2) at Reef's table sizes and relate them to the HBM
+roofline:  python tools/time_sumcheck.py [ell ...]   (cfg3: 21, cfg4 hybrid: 26)"""
+import sys, os, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from reef_amd import msm
+from reef_amd.sumcheck import SumCheck
+from oracle.sumcheck_oracle import Q
+
+for ell in [int(x) for x in sys.argv[1:]] or [21, 24, 26]:
+    n = 1 << ell
+    doc = msm.gen_scalars("pallas", 0xD0C, n, kind=0, mont=False, device=True)
+    eqv = msm.gen_scalars("pallas", 0xE9, n, kind=0, mont=False, device=True)
+    with SumCheck("pallas", ell) as sc:
+        for rep in range(2):                      # second pass is the timed one (first warms allocations)
+            sc.set_table_device(0, doc.ptr, n)
+            sc.set_table_device(1, eqv.ptr, n)
+            sc.sync()
+            t_coeff = t_fold = 0.0
+            first = None
+            t_all = time.perf_counter()
+            for i in range(1, ell + 1):
+                t0 = time.perf_counter()
+                xsq, x, con = sc.round_coeffs(i)
+                t1 = time.perf_counter()
+                sc.fold(i, (xsq * 7 + 3) % Q)     # stand-in for the Poseidon challenge
+                sc.sync()
+                t2 = time.perf_counter()
+                t_coeff += t1 - t0
+                t_fold += t2 - t1
+                if i == 1:
+                    first = (t1 - t0, t2 - t1)
+            total = time.perf_counter() - t_all
+        gb_c, gb_f = 64 * n / 1e9, 96 * n / 1e9    # round 1: coeffs read 2 tables, fold reads 2 and writes half
+        print(f"ell={ell}: all {ell} rounds {total*1e3:.2f} ms (coeffs {t_coeff*1e3:.2f}, folds {t_fold*1e3:.2f}); "
+              f"round 1: coeffs {first[0]*1e3:.3f} ms = {gb_c/first[0]:.0f} GB/s, fold {first[1]*1e3:.3f} ms = {gb_f/first[1]:.0f} GB/s "
+              f"(HBM peak 8000 GB/s)", flush=True)
+
+# CPU beside it: the oracle's C port of one round (single thread, Montgomery tables), 2^21 entries
+import numpy as np
+from oracle import pasta_ref as R
+ell = 21
+n = 1 << ell
+T = msm.gen_scalars("pallas", 0xD0C, n, kind=0, mont=False)
+E = msm.gen_scalars("pallas", 0xE9, n, kind=0, mont=False)
+R.sc_to_mont(1, T); R.sc_to_mont(1, E)
+t0 = time.perf_counter()
+R.sc_round(1, T, E, n // 2, 12345)
+dt = time.perf_counter() - t0
+print(f"CPU port (oracle/pasta_ref.c, 1 thread) round 1 at ell={ell}: {dt*1e3:.1f} ms = {160*n/dt/1e9:.2f} GB/s of table traffic")
