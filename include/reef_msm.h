@@ -169,6 +169,9 @@ reef_status reef_sc_round_coeffs(reef_sc_ctx *ctx, size_t pow, reef_fe out[3]);
 reef_status reef_sc_fold(reef_sc_ctx *ctx, size_t pow, const reef_fe *r);
 /* Read back the first `count` entries of a table as canonical integers (host). */
 reef_status reef_sc_read(reef_sc_ctx *ctx, int which, size_t count, reef_fe *out);
+/* T <- the values last given to reef_sc_set_table(ctx, 0, ..): every folding step starts from the
+ * unfolded table (the reference clones it per step, r1cs.rs:2320); device-to-device, asynchronous. */
+reef_status reef_sc_reset_table(reef_sc_ctx *ctx);
 reef_status reef_sc_sync(reef_sc_ctx *ctx);
 
 /* ---------------------------------------------------------------------------------------------

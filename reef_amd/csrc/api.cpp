@@ -243,6 +243,10 @@ reef_status reef_sc_read(reef_sc_ctx *ctx, int which, size_t count, reef_fe *out
     SC_CHECK(ctx);
     return vt(ctx->curve)->sc_read(ctx->impl, which, count, out);
 }
+reef_status reef_sc_reset_table(reef_sc_ctx *ctx) {
+    SC_CHECK(ctx);
+    return vt(ctx->curve)->sc_reset(ctx->impl);
+}
 reef_status reef_sc_sync(reef_sc_ctx *ctx) {
     SC_CHECK(ctx);
     return vt(ctx->curve)->sc_sync(ctx->impl);

@@ -91,5 +91,9 @@ class SumCheck:
         check(self._lib.reef_sc_read(self._h, which, count, out.ctypes.data))
         return array_to_ints(out)
 
+    def reset_table(self) -> None:
+        """T <- the table as last set (start of the next folding step)."""
+        check(self._lib.reef_sc_reset_table(self._h))
+
     def sync(self) -> None:
         check(self._lib.reef_sc_sync(self._h))

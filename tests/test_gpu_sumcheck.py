@@ -35,6 +35,8 @@ def test_reference_test_vectors_on_gpu(gpu_lib):
             assert sc.read(1, 1 << (3 - i)) == e[: 1 << (3 - i)]
         # prover_mle_partial_eval(table, sc_rs) == the folded table (r1cs.rs:2379-2385)
         assert sc.read(0, 1)[0] == verifier_mle_eval(evals, rs)
+        sc.reset_table()                                         # next folding step starts from the table
+        assert sc.read(0, 8) == evals
 
 
 @pytest.mark.parametrize("curve,ell,n_t", [("pallas", 10, 1000), ("pallas", 14, 1 << 14), ("vesta", 9, 300)])
