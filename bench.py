@@ -40,7 +40,7 @@ def parse():
     p.add_argument("--bucket-groups", type=int, default=-1, help="-1: engine default for the bench key")
     p.add_argument("--chunk", type=int, default=0)
     p.add_argument("--segment", type=int, default=0)
-    p.add_argument("--streams", type=int, default=2, help="MSMs in flight (clones of the key on separate HIP streams)")
+    p.add_argument("--streams", type=int, default=3, help="MSMs in flight (clones of the key on separate HIP streams)")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--cpu-seconds", type=float, default=12.0)
     p.add_argument("--no-check", action="store_true")

@@ -167,6 +167,9 @@ reef_status reef_sc_gen_eq_table(reef_sc_ctx *ctx, const reef_fe *rs, const uint
 reef_status reef_sc_round_coeffs(reef_sc_ctx *ctx, size_t pow, reef_fe out[3]);
 /* X[b] = X[b]*(1 - r) + X[b + pow]*r for b < pow, both tables, in place (asynchronous). */
 reef_status reef_sc_fold(reef_sc_ctx *ctx, size_t pow, const reef_fe *r);
+/* reef_sc_fold(pow, r) and reef_sc_round_coeffs(pow / 2) in ONE pass over the tables (pow >= 2):
+ * the fold of round i feeds the sums of round i+1 from registers. */
+reef_status reef_sc_fold_and_next_coeffs(reef_sc_ctx *ctx, size_t pow, const reef_fe *r, reef_fe out[3]);
 /* Read back the first `count` entries of a table as canonical integers (host). */
 reef_status reef_sc_read(reef_sc_ctx *ctx, int which, size_t count, reef_fe *out);
 /* T <- the values last given to reef_sc_set_table(ctx, 0, ..): every folding step starts from the

@@ -90,6 +90,7 @@ def load() -> ctypes.CDLL:
         "reef_sc_gen_eq_table": (c_int, [vp, vp, vp, c_size_t, vp, c_size_t]),
         "reef_sc_round_coeffs": (c_int, [vp, c_size_t, vp]),
         "reef_sc_fold": (c_int, [vp, c_size_t, vp]),
+        "reef_sc_fold_and_next_coeffs": (c_int, [vp, c_size_t, vp, vp]),
         "reef_sc_read": (c_int, [vp, c_int, c_size_t, vp]),
         "reef_sc_reset_table": (c_int, [vp]),
         "reef_sc_sync": (c_int, [vp]),

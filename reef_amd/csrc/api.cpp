@@ -239,6 +239,10 @@ reef_status reef_sc_fold(reef_sc_ctx *ctx, size_t pow, const reef_fe *r) {
     SC_CHECK(ctx);
     return vt(ctx->curve)->sc_fold(ctx->impl, pow, r);
 }
+reef_status reef_sc_fold_and_next_coeffs(reef_sc_ctx *ctx, size_t pow, const reef_fe *r, reef_fe out[3]) {
+    SC_CHECK(ctx);
+    return vt(ctx->curve)->sc_fold_coeffs(ctx->impl, pow, r, out);
+}
 reef_status reef_sc_read(reef_sc_ctx *ctx, int which, size_t count, reef_fe *out) {
     SC_CHECK(ctx);
     return vt(ctx->curve)->sc_read(ctx->impl, which, count, out);

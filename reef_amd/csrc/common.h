@@ -75,6 +75,7 @@ struct CurveVTable {
     reef_status (*sc_read)(void *impl, int which, size_t count, reef_fe *out_host);
     reef_status (*sc_coeffs)(void *impl, size_t pow, reef_fe *out3_host);
     reef_status (*sc_fold)(void *impl, size_t pow, const reef_fe *r);
+    reef_status (*sc_fold_coeffs)(void *impl, size_t pow, const reef_fe *r, reef_fe *out3_host);
     reef_status (*sc_gen_eq)(void *impl, const reef_fe *rs, const uint32_t *qs, size_t nq, const reef_fe *last_q, size_t ell);
     reef_status (*sc_reset)(void *impl);
     reef_status (*sc_sync)(void *impl);

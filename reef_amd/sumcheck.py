@@ -86,6 +86,14 @@ class SumCheck:
         rr = ints_to_array([r])
         check(self._lib.reef_sc_fold(self._h, 1 << (self.ell - i), rr.ctypes.data))
 
+    def fold_and_next_coeffs(self, i: int, r: int) -> Tuple[int, int, int]:
+        """fold(i, r) fused with round_coeffs(i + 1): one pass over the tables (i < ell)."""
+        rr = ints_to_array([r])
+        out = np.zeros((3, 4), dtype=np.uint64)
+        check(self._lib.reef_sc_fold_and_next_coeffs(self._h, 1 << (self.ell - i), rr.ctypes.data, out.ctypes.data))
+        xsq, x, con = array_to_ints(out)
+        return xsq, x, con
+
     def read(self, which: int, count: int) -> List[int]:
         out = np.zeros((count, 4), dtype=np.uint64)
         check(self._lib.reef_sc_read(self._h, which, count, out.ctypes.data))

@@ -102,3 +102,25 @@ def test_baseline_size_identity(gpu_lib):
             claim = (xsq * r * r + x * r + con) % Q
         t0, e0 = sc.read(0, 1)[0], sc.read(1, 1)[0]
         assert claim == t0 * e0 % Q                             # final claim = T~(r) * EQ~(r)
+
+
+def test_fused_fold_and_next_coeffs(gpu_lib):
+    """The one-pass form (fold of round i + sums of round i+1) gives the same transcript."""
+    from reef_amd.sumcheck import SumCheck
+    ell = 12
+    rng = SplitMix64(4321)
+    t = [uniform_scalar(rng, Q) for _ in range(1 << ell)]
+    e = [uniform_scalar(rng, Q) for _ in range(1 << ell)]
+    with SumCheck("pallas", ell) as sc:
+        sc.set_table(0, t)
+        sc.set_table(1, e)
+        g = sc.round_coeffs(1)
+        for i in range(1, ell + 1):
+            assert g == linear_mle_coeffs(t, e, ell, i), i
+            r = uniform_scalar(rng, Q)
+            linear_mle_fold(t, e, ell, i, r)
+            if i < ell:
+                g = sc.fold_and_next_coeffs(i, r)
+            else:
+                sc.fold(i, r)
+        assert sc.read(0, 1) == [t[0]] and sc.read(1, 1) == [e[0]]

@@ -31,6 +31,22 @@ for ell in [int(x) for x in sys.argv[1:]] or [21, 24, 26]:
                 if i == 1:
                     first = (t1 - t0, t2 - t1)
             total = time.perf_counter() - t_all
+        # fused form: one pass per round
+        sc.set_table_device(0, doc.ptr, n); sc.set_table_device(1, eqv.ptr, n); sc.sync()
+        t_f = time.perf_counter()
+        xsq, x, con = sc.round_coeffs(1)
+        t_first = None
+        for i in range(1, ell + 1):
+            rch = (xsq * 7 + 3) % Q
+            t0 = time.perf_counter()
+            if i < ell:
+                xsq, x, con = sc.fold_and_next_coeffs(i, rch)
+            else:
+                sc.fold(i, rch); sc.sync()
+            if i == 1:
+                t_first = time.perf_counter() - t0
+        total_fused = time.perf_counter() - t_f
+        print(f"ell={ell}: fused fold+coeffs: all rounds {total_fused*1e3:.2f} ms; round 1 {t_first*1e3:.3f} ms = {96*n/t_first/1e9:.0f} GB/s", flush=True)
         gb_c, gb_f = 64 * n / 1e9, 96 * n / 1e9    # round 1: coeffs read 2 tables, fold reads 2 and writes half
         print(f"ell={ell}: all {ell} rounds {total*1e3:.2f} ms (coeffs {t_coeff*1e3:.2f}, folds {t_fold*1e3:.2f}); "
               f"round 1: coeffs {first[0]*1e3:.3f} ms = {gb_c/first[0]:.0f} GB/s, fold {first[1]*1e3:.3f} ms = {gb_f/first[1]:.0f} GB/s "
