@@ -114,6 +114,18 @@ reef_status reef_msm_rows(reef_msm_ctx *ctx, const reef_fe *scalars, size_t rows
                           const reef_fe *blinds, const reef_affine *h, reef_jacobian *out,
                           int out_loc);
 
+/* IPA round WITHOUT generator folding.  After k rounds of G'_i = w1*G_i + w2*G_{i+half} the
+ * generators are fixed linear combinations of the original ones, so the cross terms of round k
+ *     L = <a_lo, G^(k)_hi>,   R = <a_hi, G^(k)_lo>        (a = a_lo || a_hi, n_k = n / 2^k scalars)
+ * are two MSMs over the ORIGINAL resident key with scalars a[.] * prod(challenges): this replaces
+ * CommitmentGens::fold + the two commits of ipa_pc::InnerProductArgument::prove [R]
+ * (CompressedSNARK::prove, src/backend/framework.rs:695; HyraxPC::prove_eval, commitment.rs:371,383)
+ * and yields bit-identical L, R.  w1s/w2s: the k challenges so far, canonical integers on the host
+ * (same convention as reef_fold); n_k * 2^k must equal the key length.  L and R go to the host. */
+reef_status reef_ipa_cross_terms(reef_msm_ctx *ctx, const reef_fe *a, size_t n_k, int a_loc, bool is_mont,
+                                 const reef_fe *w1s, const reef_fe *w2s, size_t k, reef_jacobian *out_l,
+                                 reef_jacobian *out_r);
+
 /* ---------------------------------------------------------------------------------------------
  * (3) Stateless helpers around the MSMs.
  * ------------------------------------------------------------------------------------------- */

@@ -162,6 +162,12 @@ reef_status reef_msm_plan_for(size_t n, uint32_t window_bits, uint32_t bucket_gr
     return pallas_vtable()->plan_for(n, window_bits, bucket_groups, c, windows, groups, tables);
 }
 
+reef_status reef_ipa_cross_terms(reef_msm_ctx *ctx, const reef_fe *a, size_t n_k, int a_loc, bool is_mont, const reef_fe *w1s,
+                                 const reef_fe *w2s, size_t k, reef_jacobian *out_l, reef_jacobian *out_r) {
+    if (!ctx) { set_error("null argument"); return REEF_ERR_ARG; }
+    return vt(ctx->curve)->ipa_cross(ctx->impl, a, n_k, a_loc, is_mont, w1s, w2s, k, out_l, out_r);
+}
+
 #define STATELESS_PROLOGUE(curve)          \
     const CurveVTable *v = vt(curve);      \
     if (!v) return REEF_ERR_ARG;           \

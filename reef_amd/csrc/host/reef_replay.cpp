@@ -63,6 +63,25 @@ static reef_fe *device_scalars(int curve, uint64_t seed, int kind, size_t n) {
     return p;
 }
 
+// One IPA without generator folding: every round's cross terms are two MSMs over the ORIGINAL
+// pre-shifted key with scalars a[.] * prod(challenges) (reef_ipa_cross_terms); the vector fold
+// a' = r*a_lo + r^-1*a_hi is field-only host work in nova and is not replayed.
+static double run_ipa_nofold(Curve &c, size_t n, const reef_fe *d_scalars, int *rounds_out) {
+    auto t0 = clk::now();
+    std::vector<reef_fe> w1s, w2s;
+    reef_jacobian L, R;
+    int rounds = 0;
+    for (size_t len = n; len > 1; len /= 2, ++rounds) {
+        CK(reef_ipa_cross_terms(c.key, d_scalars, len, REEF_DEVICE, true, w1s.data(), w2s.data(), w1s.size(), &L, &R));
+        reef_fe w1 = {{0x1234567890abcdefULL + rounds, 0x0fedcba987654321ULL, 0x1111111122222222ULL, 0x0333333344444444ULL}};
+        reef_fe w2 = {{0x0badc0ffee0ddf00ULL + rounds, 0x0123456789abcdefULL, 0x5555555566666666ULL, 0x0777777788888888ULL}};
+        w1s.push_back(w1);
+        w2s.push_back(w2);
+    }
+    if (rounds_out) *rounds_out = rounds;
+    return ms_since(t0);
+}
+
 // One IPA: log2(n) rounds, two cross MSMs of n/2 points on two streams + the generator fold.
 static double run_ipa(Curve &c, size_t n, const reef_fe *d_scalars, int *rounds_out) {
     auto t0 = clk::now();
@@ -97,7 +116,7 @@ int main(int argc, char **argv) {
     for (const Shape &s : SHAPES)
         if (strstr(s.name, which)) sh = &s;
     if (!sh) {
-        fprintf(stderr, "usage: reef_replay [cfg1|cfg3|cfg4|cfg5]\n");
+        fprintf(stderr, "usage: reef_replay [cfg1|cfg3|cfg4|cfg5] [nofold]\n");
         return 2;
     }
     if (reef_device_count() < 1) { fprintf(stderr, "no GPU: %s\n", reef_last_error()); return 3; }
@@ -146,8 +165,9 @@ int main(int argc, char **argv) {
     auto t_final = clk::now();
     msm(cv[1], sT2, sh->c2);  // last NIFS fold
     int r1 = 0, r2 = 0, r3 = 0;
-    const double ipa1_ms = run_ipa(cv[0], cv[0].n, sT1, &r1);
-    const double ipa2_ms = run_ipa(cv[1], cv[1].n, sT2, &r2);
+    const bool nofold = argc > 2 && strcmp(argv[2], "nofold") == 0;
+    const double ipa1_ms = nofold ? run_ipa_nofold(cv[0], cv[0].n, sT1, &r1) : run_ipa(cv[0], cv[0].n, sT1, &r1);
+    const double ipa2_ms = nofold ? run_ipa_nofold(cv[1], cv[1].n, sT2, &r2) : run_ipa(cv[1], cv[1].n, sT2, &r2);
     const double final_ms = ms_since(t_final);
 
     double cons_ms = 0;
@@ -159,11 +179,11 @@ int main(int argc, char **argv) {
     }
 
     const size_t pairs_step = sh->c2 + sh->w1 + sh->c1 + sh->w2;
-    printf("{\"replay\": \"%s\", \"note\": \"MSM work of reef --prove replayed through the C ABI; host-side proving work not included\", "
+    printf("{\"replay\": \"%s\", \"ipa\": \"%s\", \"note\": \"MSM work of reef --prove replayed through the C ABI; host-side proving work not included\", "
            "\"key_pallas\": %zu, \"key_vesta\": %zu, \"steps\": %d, \"setup_ms\": %.3f, \"fold_steps_ms\": %.3f, \"ms_per_step\": %.3f, "
            "\"pairs_per_step\": %zu, \"final_snark_ms\": %.3f, \"ipa_pallas_ms\": %.3f, \"ipa_pallas_rounds\": %d, \"ipa_vesta_ms\": %.3f, "
            "\"ipa_vesta_rounds\": %d, \"consistency_ipa_ms\": %.3f, \"consistency_rounds\": %d, \"total_prove_msm_ms\": %.3f}\n",
-           sh->name, cv[0].n, cv[1].n, sh->steps, setup_ms, steps_ms, steps_ms / sh->steps, pairs_step, final_ms, ipa1_ms, r1, ipa2_ms, r2,
+           sh->name, nofold ? "cross terms over the original key (no generator fold)" : "generator fold per round", cv[0].n, cv[1].n, sh->steps, setup_ms, steps_ms, steps_ms / sh->steps, pairs_step, final_ms, ipa1_ms, r1, ipa2_ms, r2,
            cons_ms, r3, steps_ms + final_ms + cons_ms);
     for (Curve &c : cv) {
         reef_msm_ctx_destroy(c.key);

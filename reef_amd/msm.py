@@ -185,6 +185,19 @@ class MsmContext:
         check(self._lib.reef_msm(self._h, ptr, n, loc, bool(is_mont), optr, oloc))
         return out
 
+    def ipa_cross_terms(self, a: np.ndarray, w1s, w2s, *, is_mont: bool = True):
+        """Cross terms (L, R) of IPA round k = len(w1s) over the original generators, without
+        folding them: a = a_lo || a_hi (n / 2^k scalars), w1s/w2s = challenges so far (ints)."""
+        a = np.ascontiguousarray(a, dtype=np.uint64).reshape(-1, 4)
+        k = len(w1s)
+        assert len(w2s) == k
+        w1 = np.array([list(scalar_to_limbs(w)) for w in w1s], dtype=np.uint64).reshape(k, 4) if k else np.zeros((1, 4), np.uint64)
+        w2 = np.array([list(scalar_to_limbs(w)) for w in w2s], dtype=np.uint64).reshape(k, 4) if k else np.zeros((1, 4), np.uint64)
+        out_l, out_r = np.zeros(12, dtype=np.uint64), np.zeros(12, dtype=np.uint64)
+        check(self._lib.reef_ipa_cross_terms(self._h, a.ctypes.data, a.shape[0], REEF_HOST, bool(is_mont), w1.ctypes.data,
+                                             w2.ctypes.data, k, out_l.ctypes.data, out_r.ctypes.data))
+        return out_l, out_r
+
     def msm_rows(self, scalars: Buf, rows: int, row_len: int, *, is_mont: bool = True, max_scalar_bits: int = 0,
                  blinds: Optional[Buf] = None, h: Optional[Buf] = None, out: Optional[Buf] = None) -> Buf:
         if row_len > self.n:

@@ -87,3 +87,31 @@ def test_ipa_round_shape(gpu_lib, cref):
         return P.CommitmentGens(name, aff, precompute=False).commit(P.scalars_to_array([k], name), is_mont=False)
     rhs = Cfull + scale(L, r * r % C.order) + scale(Rr, rinv * rinv % C.order)
     assert lhs == rhs
+
+
+@pytest.mark.parametrize("groups", [1, 0])
+def test_ipa_without_generator_folding(groups, gpu_lib, cref):
+    """reef_ipa_cross_terms == fold the generators k times (oracle), then the two cross MSMs."""
+    from reef_amd import msm
+    cid = 0
+    C = CURVES["pallas"]
+    n = 256
+    gens0 = cref.gen_bases_ap(cid, 21, 4, n)
+    rng = SplitMix64(77)
+    with msm.MsmContext(cid, gens0, bucket_groups=groups) as ctx:
+        gens = gens0
+        w1s, w2s = [], []
+        a = cref.gen_scalars(cid, 3, n)                       # Montgomery-form scalars
+        for k in range(0, 6):
+            n_k = n >> k
+            half = n_k // 2
+            a_k = a[:n_k].copy()
+            L, R = ctx.ipa_cross_terms(a_k, w1s, w2s)
+            exp_l = cref.msm_pippenger(cid, gens[half:n_k].copy(), a_k[:half].copy())
+            exp_r = cref.msm_pippenger(cid, gens[:half].copy(), a_k[half:].copy())
+            assert msm.compress(cid, L) == cref.compress(cid, exp_l), k
+            assert msm.compress(cid, R) == cref.compress(cid, exp_r), k
+            w1, w2 = uniform_scalar(rng, C.order), uniform_scalar(rng, C.order)
+            gens = cref.fold(cid, np.ascontiguousarray(gens[:n_k]), w1, w2)
+            w1s.append(w1)
+            w2s.append(w2)
