@@ -175,7 +175,18 @@ int main(int argc, char **argv) {
         Curve hy;
         hy.id = REEF_PALLAS; hy.n = sh->hyrax_row; hy.d_gens = cv[0].d_gens;  // prefix of the same key shape
         for (int k = 0; k < 2; ++k) hy.ipa[k] = cv[0].ipa[k];
-        cons_ms = run_ipa(hy, hy.n, sT1, &r3);
+        if (nofold) {   // the Hyrax row generators are a resident key of their own (commitment.rs:176-186)
+            reef_msm_opts o = {};
+            o.bucket_groups = 1;
+            o.device = -1;
+            CK(reef_msm_ctx_create(&hy.key, hy.id, hy.d_gens, hy.n, REEF_DEVICE, &o));
+            reef_jacobian warm_l, warm_r;
+            CK(reef_ipa_cross_terms(hy.key, sT1, hy.n, REEF_DEVICE, true, nullptr, nullptr, 0, &warm_l, &warm_r));
+            cons_ms = run_ipa_nofold(hy, hy.n, sT1, &r3);
+            reef_msm_ctx_destroy(hy.key);
+        } else {
+            cons_ms = run_ipa(hy, hy.n, sT1, &r3);
+        }
     }
 
     const size_t pairs_step = sh->c2 + sh->w1 + sh->c1 + sh->w2;
