@@ -126,6 +126,8 @@ def main():
     ctx0 = msm.MsmContext(a.curve, bases, n, window_bits=a.window_bits, bucket_groups=groups, chunk=a.chunk, segment=a.segment)
     ctxs = [ctx0] + [ctx0.clone() for _ in range(max(1, a.streams) - 1)]
     plan = ctx0.plan()
+    for c_ in ctxs:
+        c_.enable_timing(True)        # roofline.achieved needs the accumulation kernel's own duration
     nctx = len(ctxs)
     # per-context device buffers: local partial (96 B), gathered partials, combined result
     parts = [torch.zeros(96, dtype=torch.uint8, device=dev) for _ in range(nctx)]

@@ -201,6 +201,8 @@ reef_status reef_memcpy(void *dst, const void *src, size_t bytes, int dst_loc, i
 const char *reef_last_error(void);                     /* thread-local message of the last failure */
 const char *reef_version(void);
 
+/* Per-MSM HIP-event timing is opt-in (each event record costs ~6 us of stream time). */
+reef_status reef_msm_ctx_enable_timing(reef_msm_ctx *ctx, int on);
 /* Timing of the last reef_msm / reef_msm_rows on this ctx, measured with HIP events on the ctx's
  * stream (valid after a sync): total and the accumulation kernel alone, in milliseconds. */
 reef_status reef_msm_ctx_last_timing(reef_msm_ctx *ctx, float *total_ms, float *accumulate_ms);

@@ -133,6 +133,10 @@ reef_status reef_msm_ctx_last_timing(reef_msm_ctx *ctx, float *total_ms, float *
     if (!ctx) { set_error("null argument"); return REEF_ERR_ARG; }
     return vt(ctx->curve)->ctx_timing(ctx->impl, total_ms, accumulate_ms);
 }
+reef_status reef_msm_ctx_enable_timing(reef_msm_ctx *ctx, int on) {
+    if (!ctx) { set_error("null argument"); return REEF_ERR_ARG; }
+    return vt(ctx->curve)->ctx_enable_timing(ctx->impl, on);
+}
 reef_status reef_msm_ctx_timing_stats(reef_msm_ctx *ctx, int reset, uint64_t *calls, double *total_ms, double *accumulate_ms) {
     if (!ctx) { set_error("null argument"); return REEF_ERR_ARG; }
     return vt(ctx->curve)->ctx_timing_stats(ctx->impl, reset, calls, total_ms, accumulate_ms);

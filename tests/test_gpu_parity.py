@@ -283,6 +283,22 @@ def test_rows_vs_c_oracle(name, rows, row_len, bound, gpu_lib, cref):
         assert msm.compress(cid, ctx.msm_rows(sc, rows, row_len)) == exp_nb
 
 
+@pytest.mark.parametrize("name,rows,row_len,groups,kind", [("pallas", 3, 8192, 0, 0), ("vesta", 2, 9000, 1, 0),
+                                                          ("pallas", 5, 8200, 1, 1), ("pallas", 2, 16384, 4, 0)])
+def test_long_rows_batched_slice_sort(name, rows, row_len, groups, kind, gpu_lib, cref):
+    """Rows of K1 size (>= 8192 wide scalars) go through the sliced sort as one batch of MSMs."""
+    from reef_amd import msm
+    cid = CID[name]
+    bases = cref.gen_bases_ap(cid, 5, 3, row_len)
+    sc = cref.gen_scalars(cid, 99, rows * row_len, kind=kind)
+    bl = cref.gen_scalars(cid, 5, rows)
+    h = cref.gen_bases_ap(cid, 0xB11D, 1, 1)[0].copy()
+    exp = cref.compress(cid, cref.row_msm(cid, bases, sc, rows, row_len, h=h, blinds=bl, threads=8))
+    with msm.MsmContext(cid, bases, bucket_groups=groups) as ctx:
+        assert msm.compress(cid, ctx.msm_rows(sc, rows, row_len, blinds=bl, h=h)) == exp
+        assert msm.compress(cid, ctx.msm_rows(sc, rows, row_len, blinds=bl, h=h, max_scalar_bits=255)) == exp
+
+
 def test_fold_golden_and_oracle(golden, gpu_lib, cref):
     from reef_amd import msm
     for case in golden["fold"]:

@@ -10,6 +10,7 @@ bases = msm.gen_bases("pallas", 12345, 7, n, device=True)
 sc = msm.gen_scalars("pallas", 99, n, kind=0, device=True)
 out = msm.DeviceBuffer(96)
 ctx = msm.MsmContext("pallas", bases, n, window_bits=c, bucket_groups=g)
+ctx.enable_timing(True)
 for _ in range(reps):
     ctx.msm(sc, n, out=out)
     ctx.sync()

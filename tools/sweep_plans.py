@@ -14,6 +14,7 @@ def run(logn, c, g, kind=0, reps=6, chunk=0, seg=0):
         ctx = msm.MsmContext("pallas", bases, n, window_bits=c, bucket_groups=g, chunk=chunk, segment=seg)
     except msm.ReefError as e:
         return None
+    ctx.enable_timing(True)
     for _ in range(2):
         ctx.msm(sc, n, out=out)
     ctx.sync(); ctx.timing_stats(reset=True)

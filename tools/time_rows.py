@@ -13,6 +13,7 @@ bases = msm.gen_bases("pallas", k0, d, row_len, device=True)
 sc = msm.gen_scalars("pallas", 0xD0C, rows * row_len, kind=2, small_bound=bound, mont=True, device=True)
 out = msm.DeviceBuffer(96 * rows)
 ctx = msm.MsmContext("pallas", bases, row_len)
+ctx.enable_timing(True)
 ctx.msm_rows(sc, rows, row_len, out=out); ctx.sync()
 t0 = time.perf_counter()
 for _ in range(reps):
