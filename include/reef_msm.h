@@ -190,6 +190,33 @@ reef_status reef_sc_reset_table(reef_sc_ctx *ctx);
 reef_status reef_sc_sync(reef_sc_ctx *ctx);
 
 /* ---------------------------------------------------------------------------------------------
+ * (3c) Row N3: the O(N) field passes over the committed document at proof end, over the SCALAR
+ *      field of `curve`.
+ *
+ * Replaces, in NLDocCommitment::proof_dot_prod_prover (src/backend/commitment.rs:287-405):
+ *   doc_poly.evaluate(&running_q)                               commitment.rs:357
+ *   the bound rows LZ = L^T Z inside hyrax_gen.prove_eval(..)   commitment.rs:371-379, :383-391
+ *   (the dot-product IPA over LZ that follows runs on reef_msm / reef_ipa_cross_terms)
+ * and verifier_mle_eval(table, q') of prove_consistency (commitment.rs:236; r1cs_helper.rs:637-641).
+ *
+ * z: the table, n entries (n <= 2^num_vars; the rest is zero padding), row-major as the
+ * 2^left_vars x 2^(num_vars-left_vars) matrix Hyrax commits to (compute_factored_lens,
+ * commitment.rs:173-174).  elem_bytes = 32: field elements in the same form as `point`
+ * (is_mont: pasta ABI Montgomery form, else canonical integers); elem_bytes = 1, 2 or 4: unsigned
+ * little-endian document symbols (framework.rs:978-1011).  point[0] pairs with the most
+ * significant index bit (r1cs_helper.rs:577-592).
+ *
+ *   lz_out[j]  = sum_i eq(point[..left_vars], i) * z[i * 2^(num_vars-left_vars) + j]
+ *   *eval_out  = sum_j lz[j] * eq(point[left_vars..], j)     (= the multilinear extension at point)
+ *
+ * Either output may be NULL.  Outputs are in the form `is_mont` names; eval_out is host memory.
+ * Blind combination sum_i L_i * blind_i: the same call with the blinds as a one-column table
+ * (num_vars = left_vars). */
+reef_status reef_mle_bound_rows(int curve, const void *z, size_t n, int elem_bytes, int z_loc, bool is_mont,
+                                const reef_fe *point, size_t num_vars, size_t left_vars, reef_fe *lz_out, int out_loc,
+                                reef_fe *eval_out);
+
+/* ---------------------------------------------------------------------------------------------
  * (4) Runtime plumbing.
  * ------------------------------------------------------------------------------------------- */
 int reef_device_count(void);

@@ -68,6 +68,7 @@ def load() -> ctypes.CDLL:
         "reef_ipa_cross_terms": (c_int, [vp, vp, c_size_t, c_int, c_bool, vp, vp, c_size_t, vp, vp]),
         "reef_fold": (c_int, [c_int, vp, c_size_t, c_int, vp, vp, vp]),
         "reef_normalize": (c_int, [c_int, vp, c_size_t, c_int, vp, vp]),
+        "reef_mle_bound_rows": (c_int, [c_int, vp, c_size_t, c_int, c_int, c_bool, vp, c_size_t, c_size_t, vp, c_int, vp]),
         "reef_sum_points": (c_int, [c_int, vp, c_size_t, c_int, vp]),
         "reef_gen_bases": (c_int, [c_int, c_uint64, c_uint64, c_size_t, vp, c_int]),
         "reef_gen_scalars": (c_int, [c_int, c_uint64, c_int, c_uint64, c_size_t, c_bool, vp, c_int]),

@@ -182,6 +182,11 @@ reef_status reef_fold(int curve, const reef_affine *gens, size_t half, int loc, 
     STATELESS_PROLOGUE(curve);
     return v->fold(gens, half, loc, w1, w2, out);
 }
+reef_status reef_mle_bound_rows(int curve, const void *z, size_t n, int elem_bytes, int z_loc, bool is_mont, const reef_fe *point,
+                                size_t num_vars, size_t left_vars, reef_fe *lz_out, int out_loc, reef_fe *eval_out) {
+    STATELESS_PROLOGUE(curve);
+    return v->mle_bound(z, n, elem_bytes, z_loc, is_mont, point, num_vars, left_vars, lz_out, out_loc, eval_out);
+}
 reef_status reef_normalize(int curve, const reef_jacobian *in, size_t n, int loc, reef_affine *out_affine, uint8_t *out_compressed) {
     STATELESS_PROLOGUE(curve);
     return v->normalize(in, n, loc, out_affine, out_compressed);

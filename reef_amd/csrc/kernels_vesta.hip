@@ -2,6 +2,7 @@
 #define REEF_CURVE 1
 #include "msm_kernels.inc"
 #include "sumcheck_kernels.inc"
+#include "mle_kernels.inc"
 #include "engine.inc"
 namespace reef {
 const CurveVTable *vesta_vtable() {

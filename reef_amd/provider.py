@@ -166,3 +166,18 @@ class HyraxPC:
                                               blinds=blinds, h=self.gens_v.h)
         comp = msm.normalize(self.gens_v.curve, out, affine=False, compressed=True)[1]
         return out, comp
+
+    def bind_rows(self, poly, blinds: np.ndarray, point: np.ndarray, *, is_mont: bool = True, n=None, elem_bytes=None):
+        """First step of HyraxPC::prove_eval (src/backend/commitment.rs:371-391): with (L, R) the
+        eq-evaluations of the two halves of `point`, returns (LZ = L^T Z, eval = <LZ, R>,
+        LZ_blind = <L, blinds>) in the form `is_mont` names.  `poly` is an (n, 4) uint64 array of
+        field elements, a uint8/16/32 symbol array, or a device buffer (then give n, elem_bytes);
+        the dot-product IPA over LZ that follows uses `CommitmentGens.commit` / `ipa_cross_terms`."""
+        from . import mle
+        point = np.ascontiguousarray(point, dtype=np.uint64).reshape(-1, 4)
+        left, _ = self.compute_factored_lens(point.shape[0])
+        lz, ev = mle.bound_rows_raw(self.gens_v.curve, poly, point, left, is_mont=is_mont, n=n, elem_bytes=elem_bytes)
+        blinds = np.ascontiguousarray(blinds, dtype=np.uint64).reshape(1 << left, 4)
+        lz_blind, _ = mle.bound_rows_raw(self.gens_v.curve, blinds, point[:left], left, is_mont=is_mont)
+        return lz, ev, lz_blind[0]
+

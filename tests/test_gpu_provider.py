@@ -115,3 +115,36 @@ def test_ipa_without_generator_folding(groups, gpu_lib, cref):
             gens = cref.fold(cid, np.ascontiguousarray(gens[:n_k]), w1, w2)
             w1s.append(w1)
             w2s.append(w2)
+
+
+def test_hyrax_bind_rows_is_consistent_with_commit(gpu_lib, cref):
+    """prove_eval's row binding (commitment.rs:371-391): commit(LZ; LZ_blind) must equal
+    sum_i L_i * C_i over the row commitments -- the relation the Hyrax verifier checks."""
+    from oracle import mle_oracle
+    from oracle.pasta_oracle import Q, SplitMix64
+    from reef_amd import msm
+    from reef_amd.provider import CommitmentGens, HyraxPC
+    from reef_amd.sumcheck import array_to_ints, ints_to_array
+    m, left, right = 9, 4, 5
+    rows, cols = 1 << left, 1 << right
+    gens = cref.gen_bases_ap(0, 3, 7, cols)
+    h = cref.gen_bases_ap(0, 0xB11D, 1, 1)[0].copy()
+    pc = HyraxPC(CommitmentGens("pallas", gens, h))
+    z = cref.gen_scalars(0, 11, rows * cols, kind=2, small_bound=131)
+    blinds = cref.gen_scalars(0, 12, rows)
+    comms, _ = pc.commit(z, blinds)
+    rng = SplitMix64(3)
+    R = 1 << 256
+    point = [(rng.next() << 190 | rng.next()) % Q for _ in range(m)]
+    pm = ints_to_array([v * R % Q for v in point])
+    lz, ev, lz_blind = pc.bind_rows(z, blinds, pm)
+    # left side: one commitment to LZ with blind LZ_blind
+    lhs = cref.row_msm(0, gens, np.ascontiguousarray(lz), 1, cols, h=h, blinds=lz_blind.reshape(1, 4))
+    # right side: sum_i L_i * C_i  (L in Montgomery form as scalars of an MSM over the row commitments)
+    L = mle_oracle.eq_evals(point[:left], Q)
+    aff = cref.to_affine(0, comms)
+    rhs = cref.msm_naive(0, aff, ints_to_array([v * R % Q for v in L]))
+    assert cref.compress(0, lhs) == cref.compress(0, rhs)
+    zi = [v * pow(R, -1, Q) % Q for v in array_to_ints(z)]
+    assert array_to_ints(ev)[0] == mle_oracle.evaluate(zi, point, Q) * R % Q
+
