@@ -132,8 +132,8 @@ template <int C> REEF_HD xyzz xyzz_madd_flag(const xyzz &a, bool a_known_empty, 
         for (int i = 0; i < 9; ++i) t.l[i] = ppp.l[i] + 2u * q.l[i];   // limbs < 3 * 2^29 < 2^31 - 4
         REEF_SET_BOUND(t, REEF_GET_BOUND(ppp) + 2.0 * REEF_GET_BOUND(q));
         r.x = fe_sqr_sub<C, 4>(rr, t);                        // 1.2 + 4     -> < 5.2   (t < 4)
-        const fe m2 = fe_mul<C>(a.y, ppp);                    // 4.5/128     -> < 1.04
-        r.y = fe_mul_sub<C, 2>(rr, fe_sub<C, 8>(q, r.x), m2); // 5.04*9.11 = 46 -> 1.36 + 2 -> < 3.4
+        // Y3 = R*(Q - X3) + (-Y1)*PPP: both products share one reduction
+        r.y = fe_mul2_add<C>(rr, fe_sub<C, 8>(q, r.x), fe_neg<C, 4>(a.y), ppp);   // (5.04*9.11 + 4*1.12)/128 -> < 1.4
         r.zz = fe_mul<C>(a.zz, pp);                           // < 1.03
         r.zzz = fe_mul<C>(a.zzz, ppp);                        // < 1.02
     }
@@ -167,8 +167,7 @@ template <int C> REEF_HD xyzz xyzz_add(const xyzz &a, const xyzz &b) {
         const fe q = fe_mul<C>(u1, pp);                       //             -> < 1.01
         const fe t = fe_add<C>(ppp, fe_dbl<C>(q));            // < 3.05
         r.x = fe_sub<C, 4>(fe_sqr<C>(rr), t);                 // 1.08 + 4    -> < 5.1
-        r.y = fe_sub<C, 2>(fe_mul<C>(rr, fe_sub<C, 8>(q, r.x)),  // 3.07*9.01 -> < 1.22
-                           fe_mul<C>(s1, ppp));               // < 1.01 < 2  ; y3 < 3.3
+        r.y = fe_mul2_add<C>(rr, fe_sub<C, 8>(q, r.x), fe_neg<C, 2>(s1), ppp);   // (3.07*9.01 + 3.07*1.03)/128 -> < 1.25
         r.zz = fe_mul<C>(fe_mul<C>(a.zz, b.zz), pp);          // < 1.01
         r.zzz = fe_mul<C>(fe_mul<C>(a.zzz, b.zzz), ppp);      // < 1.01
     }

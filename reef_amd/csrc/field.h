@@ -185,6 +185,9 @@ REEF_HD void mad_row_acc(u64 (&t)[10], const u32 (&a)[9], u32 b) {
     for (int j = 0; j < 8; ++j) t[j] += (u64)a[j] * b;
     t[8] = (u64)a[8] * b;
 }
+REEF_HD void mad_row_add(u64 (&t)[10], const u32 (&a)[9], u32 b) {
+    for (int j = 0; j < 9; ++j) t[j] += (u64)a[j] * b;
+}
 REEF_HD void mad_reduce(u64 (&t)[10], u32 q, u32 m1, u32 m2, u32 m3, u32 m4, u32 top) {
     t[0] += q;
     t[1] += (u64)q * m1; t[2] += (u64)q * m2; t[3] += (u64)q * m3; t[4] += (u64)q * m4;
@@ -266,6 +269,32 @@ template <int F> REEF_HD fe fe_mul(const fe &a, const fe &b) {
     }
     fe r = mont_finish<F>(t);
     REEF_SET_BOUND(r, 1.0 + REEF_GET_BOUND(a) * REEF_GET_BOUND(b) / 128.0);
+    return r;
+}
+
+// (a*b + c*d)/R' mod M with one reduction: two product rows per round feed the same column
+// accumulators (18 products and 9 reduction terms of < 2^58 per column stay below 2^63).
+// Inputs normalised with (A/M)(B/M) + (C/M)(D/M) < 128; output exact 29-bit limbs, value < 2M.
+template <int F> REEF_HD fe fe_mul2_add(const fe &a, const fe &b, const fe &c, const fe &d) {
+#if defined(REEF_BOUNDS)
+    if (a.bound * b.bound + c.bound * d.bound >= 128.0) REEF_BOUND_FAIL("fe_mul2_add: (A/M)(B/M) + (C/M)(D/M) >= 128");
+    for (int i = 0; i < 8; ++i)
+        if (a.l[i] > LIMB_MASK + 8 || b.l[i] > LIMB_MASK + 8 || c.l[i] > LIMB_MASK + 8 || d.l[i] > LIMB_MASK + 8)
+            REEF_BOUND_FAIL("fe_mul2_add: operand not normalised");
+#endif
+    u64 t[10];
+    t[9] = 0;
+    mad_row_new(t, a.l, b.l[0]);
+    mad_row_add(t, c.l, d.l[0]);
+    mont_round<F>(t);
+#pragma unroll
+    for (int i = 1; i < 9; ++i) {
+        mad_row_acc(t, a.l, b.l[i]);
+        mad_row_add(t, c.l, d.l[i]);
+        mont_round<F>(t);
+    }
+    fe r = mont_finish<F>(t);
+    REEF_SET_BOUND(r, 1.0 + (REEF_GET_BOUND(a) * REEF_GET_BOUND(b) + REEF_GET_BOUND(c) * REEF_GET_BOUND(d)) / 128.0);
     return r;
 }
 
