@@ -26,6 +26,7 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 BYTES_PER_PAIR = 96            # 32 B scalar + 64 B affine base, each read once
+FMUL_PEAK = 1.57e11            # Montgomery products/s chip-wide, measured (reef_bench_fmul, profiles/README.md)
 
 
 def parse():
@@ -44,6 +45,9 @@ def parse():
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--cpu-seconds", type=float, default=12.0)
     p.add_argument("--no-check", action="store_true")
+    p.add_argument("--exercise-collective", action="store_true",
+                   help="with --gpus 1: run the N > 1 code path (process group of one rank, all_gather + on-device combine) "
+                        "to check the RCCL/stream plumbing on a single-GPU box")
     p.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                    help="nccl = RCCL over xGMI (default); gloo = host-staged gather (debug / boxes without RCCL), labelled as such")
     return p.parse_args()
@@ -109,7 +113,18 @@ def main():
     torch.cuda.set_device(dev_index)
     msm.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
-    if a.gpus > 1:
+    multi = a.gpus > 1 or a.exercise_collective      # the path with an exchange step
+    # stdout carries exactly one JSON line: RCCL prints a version banner to the C-level stdout at
+    # exit, so fd 1 is pointed at stderr for the life of the process and the line goes to a saved copy
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+    if multi:
+        if world == 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29517")
+            os.environ.setdefault("RANK", "0")
+            os.environ.setdefault("WORLD_SIZE", "1")
         if a.backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)
         else:
@@ -134,7 +149,7 @@ def main():
     gathered = [torch.zeros(96 * a.gpus, dtype=torch.uint8, device=dev) for _ in range(nctx)]
     results = [torch.zeros(96, dtype=torch.uint8, device=dev) for _ in range(nctx)]
     ext = None
-    if a.gpus > 1 and a.backend == "nccl":
+    if multi and a.backend == "nccl":
         try:                       # run the collective on the MSM's own HIP stream (no host sync per step)
             ext = [torch.cuda.ExternalStream(c.stream, device=dev) for c in ctxs]
         except Exception as e:     # older torch: fall back to a host sync before the collective
@@ -144,7 +159,7 @@ def main():
     def step(i):
         j = i % nctx
         c = ctxs[j]
-        if a.gpus == 1:
+        if not multi:
             c.msm(scalars, n, out=results[j].data_ptr())
         else:
             c.msm(scalars, n, out=parts[j].data_ptr())
@@ -169,23 +184,30 @@ def main():
             c.sync()
         torch.cuda.synchronize()
 
+    if multi and ext is not None:
+        try:                       # first collective on an external stream: fall back to host-ordered calls if torch refuses
+            step(0)
+            sync_all()
+        except Exception as e:
+            print(f"[bench] collective on the MSM stream failed ({e}); ordering by host sync instead", file=sys.stderr)
+            ext = None
     for i in range(a.warmup):
         step(i)
     sync_all()
     for c in ctxs:
         c.timing_stats(reset=True)
-    if a.gpus > 1:
+    if multi:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for i in range(a.steps):
         step(i)
     sync_all()
-    if a.gpus > 1:
+    if multi:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    if a.gpus > 1:
+    if multi:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev if a.backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -200,9 +222,9 @@ def main():
         # size-independent parity check of the last result (outside the timed region)
         canon = msm.gen_scalars(a.curve, seed, n, kind=kind, mont=False)
         local = expected_via_dlog(a.curve, canon, k0, d, rank * n)
-        got_local = msm.compress(a.curve, (parts if a.gpus > 1 else results)[(a.steps - 1) % nctx].cpu().numpy().view(np.uint64))
+        got_local = msm.compress(a.curve, (parts if multi else results)[(a.steps - 1) % nctx].cpu().numpy().view(np.uint64))
         ok = got_local == local
-        if a.gpus > 1:
+        if multi:
             cdev = dev if a.backend == "nccl" else "cpu"
             flag = torch.tensor([1 if ok else 0], device=cdev)
             dist.all_reduce(flag, op=dist.ReduceOp.MIN)
@@ -228,6 +250,7 @@ def main():
         pairs = n * a.gpus * a.steps
         value = pairs / elapsed
         achieved = BYTES_PER_PAIR * n / (acc_ms * 1e-3) / 1e9 if acc_ms > 0 else None
+        eff_windows = min(plan["windows"], -(-255 // plan["window_bits"]))   # windows that hold scalar bits (scalars < 2^255)
         out = {
             "metric": "msm_scalar_point_pairs_per_sec", "value": value, "unit": "pairs/s", "n_gpus": a.gpus,
             "steps": a.steps, "warmup": a.warmup, "ms_per_step": elapsed / a.steps * 1e3, "higher_is_better": True,
@@ -243,12 +266,17 @@ def main():
             "roofline": {"bound": "hbm", "kernel": "k_accum0 (bucket accumulation)", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": traffic,
                          "traffic_source": "profiles/r01_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes)" if traffic else None,
-                         "kernel_ms": acc_ms, "algorithmic_bytes_per_launch": BYTES_PER_PAIR * n},
+                         "kernel_ms": acc_ms, "algorithmic_bytes_per_launch": BYTES_PER_PAIR * n,
+                         # the kernel is bound by integer issue, not HBM: whole-job field products per second
+                         # (10 per bucket addition, one addition per non-zero digit ~ windows-1 per pair) against the
+                         # measured chip-wide rate of the Montgomery product (reef_bench_fmul)
+                         "issue": {"field_products_per_s": value / a.gpus * eff_windows * 10, "peak": FMUL_PEAK,
+                                   "frac": value / a.gpus * eff_windows * 10 / FMUL_PEAK, "unit": "products/s"}},
         }
         if a.gpus == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(msm.curve_id(a.curve), a.cpu_seconds)
-        print(json.dumps(out), flush=True)
-    if a.gpus > 1:
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
+    if multi:
         dist.barrier()
         dist.destroy_process_group()
     if check == "MISMATCH":

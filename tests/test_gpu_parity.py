@@ -355,3 +355,22 @@ def test_rows_baseline_size_dlog_property(rows, row_len, bound, gpu_lib):
     for r in list(range(0, rows, 97)) + [rows - 1]:
         acc = int((canon[r] * w).sum()) % C.order
         assert comp[32 * r:32 * r + 32] == C.compress(C.mul(acc, C.gen)), r
+
+
+def test_bench_collective_path_on_one_gpu(gpu_lib):
+    """bench.py's N > 1 code path (RCCL all_gather of the 96-byte partial sums on the MSM's own HIP
+    stream + on-device combine) with a process group of one rank, small size: the JSON line must
+    carry a passing parity check."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29531")
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--exercise-collective", "--logn", "14", "--steps", "4",
+                          "--warmup", "1", "--no-cpu-baseline"], capture_output=True, text=True, timeout=600, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = json.loads(out.stdout.strip().splitlines()[-1])
+    assert line["config"]["check"] == "dlog-ok" and line["n_gpus"] == 1
+    assert line["roofline"]["achieved"] > 0 and line["roofline"]["kernel_ms"] > 0
+
