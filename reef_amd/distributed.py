@@ -8,6 +8,10 @@ all-gather followed by N-1 on-device additions, identical on every rank).  A win
 rank keeps all points, owns windows w = r mod N) is provided for comparison: same exchange, but it
 replicates the key and the scalar upload, so it is not the default.
 
+Independent units need no split at all (8e.1): the rows of a Hyrax commitment share the row
+generators (replicated, resident) and are dealt out in contiguous blocks, `sharded_rows`; the only
+exchange is an all-gather of the row commitments.
+
 The arithmetic is injected (`local_msm`, `add_points`): on the GPU box these are the C-ABI calls of
 reef_amd.msm; the world_size-2 gloo tests on CPU inject the oracle as a stand-in to check the
 sharding, the exchange and the combination order.  There is no CPU fallback in the product path.
@@ -79,3 +83,27 @@ def window_sharded_msm(local_window_sums: Callable[[List[int]], List[np.ndarray]
         for k, w in enumerate([w for w in range(n_windows) if window_owner(w, world) == r]):
             all_sums[w] = arr[k]
     return combine_windows(all_sums)
+
+
+def sharded_rows(local_rows: Callable[[int, int], np.ndarray], rows: int, width: int, group=None) -> np.ndarray:
+    """Row-sharded batch of independent MSMs (HyraxPC::commit, src/backend/commitment.rs:187): rank
+    r computes the commitments of rows [lo, hi) with `local_rows(lo, hi)` -> (hi - lo, width) uint64
+    (width 12: Jacobian points, 4: compressed commitments); one all-gather returns all `rows`
+    commitments, in row order, on every rank."""
+    import torch
+    import torch.distributed as dist
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    lo, hi = shard_bounds(rows, world, rank)
+    per_rank = -(-rows // world) if rows else 0
+    mine = np.zeros((per_rank, width), dtype=np.uint64)
+    if hi > lo:
+        mine[: hi - lo] = np.ascontiguousarray(local_rows(lo, hi), dtype=np.uint64).reshape(hi - lo, width)
+    t = torch.from_numpy(mine.view(np.int64).copy())
+    out = [torch.empty_like(t) for _ in range(world)]
+    dist.all_gather(out, t, group=group)
+    res = np.zeros((rows, width), dtype=np.uint64)
+    for r in range(world):
+        a, b = shard_bounds(rows, world, r)
+        res[a:b] = out[r].numpy().view(np.uint64)[: b - a]
+    return res
+

@@ -80,7 +80,21 @@ def _worker(rank, world, port, n, results):
             return R.msm_naive(cid, aff, sc, mont=False)
 
         wcomp = R.compress(cid, D.window_sharded_msm(window_sums, combine, W))
-        results[rank] = (comp == expect, wcomp == expect, comp.hex())
+
+        # row sharding (Hyrax commit): 5 rows over the same 64 generators, dealt out as 3 + 2
+        rows, row_len = 5, 64
+        rb = bases[:row_len].copy()
+        rs = R.gen_scalars(cid, 7, rows * row_len, kind=2, small_bound=131)
+        bl = R.gen_scalars(cid, 8, rows)
+        h = R.gen_bases_ap(cid, 0xB11D, 1, 1)[0].copy()
+
+        def local_rows(lo, hi):
+            return R.row_msm(cid, rb, rs[lo * row_len:hi * row_len].copy(), hi - lo, row_len, h=h, blinds=bl[lo:hi].copy())
+
+        got_rows = D.sharded_rows(local_rows, rows, 12)
+        want_rows = R.row_msm(cid, rb, rs, rows, row_len, h=h, blinds=bl)
+        rows_ok = R.compress(cid, got_rows) == R.compress(cid, want_rows)
+        results[rank] = (comp == expect, wcomp == expect, comp.hex(), rows_ok)
     finally:
         dist.destroy_process_group()
 
@@ -95,3 +109,4 @@ def test_sharded_msm_world2(n):
     assert all(results[r][0] for r in range(world)), "point-sharded result differs from the single-rank MSM"
     assert all(results[r][1] for r in range(world)), "window-sharded result differs from the single-rank MSM"
     assert results[0][2] == results[1][2], "ranks disagree on the combined point"
+    assert all(results[r][3] for r in range(world)), "row-sharded commitments differ from the single-rank batch"
