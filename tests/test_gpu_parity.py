@@ -172,6 +172,33 @@ def test_skewed_and_degenerate_inputs(name, gpu_lib, cref):
         assert msm.compress(cid, ctx.msm(sc, is_mont=False)) == C.compress(pt)
 
 
+@pytest.mark.parametrize("name", ["pallas", "vesta"])
+def test_ragged_sizes_prefixes_and_holes(name, gpu_lib, cref):
+    """Every size around the wave / workgroup / pasta-msm dispatch edges (n = 128 is where nova switches
+    to the C symbol), through the stateless symbol and as prefixes of one resident key, with identity
+    bases and zero scalars sprinkled in (affine (0,0) and scalar 0 must both vanish)."""
+    from reef_amd import msm
+    cid = CID[name]
+    nmax = 4100
+    bases = cref.gen_bases_ap(cid, 21, 4, nmax)
+    sc = cref.gen_scalars(cid, 404, nmax, kind=1)
+    bases[5] = 0                     # identity base with a non-zero scalar
+    bases[130] = 0
+    sc[6] = 0                        # zero scalar on a real base
+    sc[131] = 0
+    bases[300] = 0
+    sc[300] = 0                      # both
+    sizes = [1, 2, 3, 63, 64, 65, 127, 128, 129, 255, 256, 257, 1023, 1024, 1025, 4095, 4096, 4097, nmax]
+    want = {n: cref.compress(cid, cref.msm_pippenger(cid, bases[:n].copy(), sc[:n].copy(), threads=4)) for n in sizes}
+    for n in sizes:
+        assert msm.compress(cid, msm.mult_pippenger(cid, bases[:n].copy(), sc[:n].copy())) == want[n], n
+    for groups in (0, 1):
+        with msm.MsmContext(cid, bases, bucket_groups=groups) as ctx:
+            for n in sizes:
+                assert msm.compress(cid, ctx.msm(sc[:n].copy())) == want[n], (groups, n)
+            assert msm.compress(cid, ctx.msm(np.zeros((0, 4), dtype=np.uint64))) == bytes(32)   # empty MSM
+
+
 @pytest.mark.parametrize("name,logn,kind,groups", [("pallas", 20, 0, 0), ("pallas", 20, 1, 0), ("vesta", 18, 0, 0),
                                                    ("pallas", 18, 0, 1), ("vesta", 17, 1, 1)])
 def test_full_size_dlog_property(name, logn, kind, groups, gpu_lib):
