@@ -25,13 +25,14 @@ def run(logn, c, g, kind=0, reps=6, chunk=0, seg=0):
     ctx.close()
     return st["total_ms"] / st["calls"], st["accumulate_ms"] / st["calls"]
 
-logns = [int(x) for x in sys.argv[1:]] or [14, 16, 17, 20]
-for logn in logns:
-    for g in (1, 0):
-        best = None
-        for c in range(max(6, logn - 8), min(20, logn + 1) + 1):
-            r = run(logn, c, g)
-            if r is None: continue
-            print(f"logn={logn} G={'1' if g==1 else 'W'} c={c:2d} total_ms={r[0]:.3f} accum_ms={r[1]:.3f}", flush=True)
-            if best is None or r[0] < best[1]: best = (c, r[0])
-        print(f"## logn={logn} G={'1' if g==1 else 'W'} best c={best[0]} {best[1]:.3f} ms  -> {(1<<logn)/best[1]/1e3:.1f} Mpairs/s", flush=True)
+if __name__ == "__main__":
+    logns = [int(x) for x in sys.argv[1:]] or [14, 16, 17, 20]
+    for logn in logns:
+        for g in (1, 0):
+            best = None
+            for c in range(max(6, logn - 8), min(20, logn + 1) + 1):
+                r = run(logn, c, g)
+                if r is None: continue
+                print(f"logn={logn} G={'1' if g==1 else 'W'} c={c:2d} total_ms={r[0]:.3f} accum_ms={r[1]:.3f}", flush=True)
+                if best is None or r[0] < best[1]: best = (c, r[0])
+            print(f"## logn={logn} G={'1' if g==1 else 'W'} best c={best[0]} {best[1]:.3f} ms  -> {(1<<logn)/best[1]/1e3:.1f} Mpairs/s", flush=True)
