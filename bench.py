@@ -48,6 +48,9 @@ def parse():
     p.add_argument("--exercise-collective", action="store_true",
                    help="with --gpus 1: run the N > 1 code path (process group of one rank, all_gather + on-device combine) "
                         "to check the RCCL/stream plumbing on a single-GPU box")
+    p.add_argument("--sharding", default="points", choices=["points", "windows"],
+                   help="N > 1: 'points' = every GPU owns its own 2^logn pairs of one N*2^logn-point MSM (weak scaling, default); "
+                        "'windows' = ONE 2^logn-point MSM, GPU r accumulates the Pippenger windows w = r mod N (strong scaling)")
     p.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                    help="nccl = RCCL over xGMI (default); gloo = host-staged gather (debug / boxes without RCCL), labelled as such")
     return p.parse_args()
@@ -132,13 +135,17 @@ def main():
     n = 1 << a.logn
     k0, d = 0xABCDEF, 0x12345
     kind = 0 if a.scalars == "uniform" else 1
-    seed = 0x5EEF + rank
+    by_windows = a.sharding == "windows" and multi
+    owner = 0 if by_windows else rank            # window split: every rank holds the same points and scalars
+    seed = 0x5EEF + owner
     groups = a.bucket_groups if a.bucket_groups >= 0 else 1   # bench key: full precompute (fixed commitment key)
 
     # synthetic inputs, generated on the device: rank r owns bases B_i, i in [r*n, (r+1)*n)
-    bases = msm.gen_bases(a.curve, k0 + rank * n * d, d, n, device=True)
+    bases = msm.gen_bases(a.curve, k0 + owner * n * d, d, n, device=True)
     scalars = msm.gen_scalars(a.curve, seed, n, kind=kind, mont=True, device=True)
     ctx0 = msm.MsmContext(a.curve, bases, n, window_bits=a.window_bits, bucket_groups=groups, chunk=a.chunk, segment=a.segment)
+    if by_windows:
+        ctx0.set_window_split(rank, max(world, 1))
     ctxs = [ctx0] + [ctx0.clone() for _ in range(max(1, a.streams) - 1)]
     plan = ctx0.plan()
     for c_ in ctxs:
@@ -221,8 +228,10 @@ def main():
     if not a.no_check:
         # size-independent parity check of the last result (outside the timed region)
         canon = msm.gen_scalars(a.curve, seed, n, kind=kind, mont=False)
-        local = expected_via_dlog(a.curve, canon, k0, d, rank * n)
-        got_local = msm.compress(a.curve, (parts if multi else results)[(a.steps - 1) % nctx].cpu().numpy().view(np.uint64))
+        local = expected_via_dlog(a.curve, canon, k0, d, owner * n)
+        # points: each rank's partial is its own slice's MSM; windows: only the combined point is an MSM
+        checked = results if (by_windows or not multi) else parts
+        got_local = msm.compress(a.curve, checked[(a.steps - 1) % nctx].cpu().numpy().view(np.uint64))
         ok = got_local == local
         if multi:
             cdev = dev if a.backend == "nccl" else "cpu"
@@ -247,19 +256,19 @@ def main():
                 traffic = prof["kernels"]["k_accum0<0>"]["hbm_bytes_per_launch"]
         except (OSError, KeyError, ValueError):
             pass
-        pairs = n * a.gpus * a.steps
+        pairs = n * (1 if by_windows else a.gpus) * a.steps
         value = pairs / elapsed
         achieved = BYTES_PER_PAIR * n / (acc_ms * 1e-3) / 1e9 if acc_ms > 0 else None
         eff_windows = min(plan["windows"], -(-255 // plan["window_bits"]))   # windows that hold scalar bits (scalars < 2^255)
         out = {
             "metric": "msm_scalar_point_pairs_per_sec", "value": value, "unit": "pairs/s", "n_gpus": a.gpus,
             "steps": a.steps, "warmup": a.warmup, "ms_per_step": elapsed / a.steps * 1e3, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "u32", "data": "synthetic",
+            "scaling": "strong" if by_windows else "weak", "vs_baseline": None, "dtype": "u32", "data": "synthetic",
             "config": {"workload": f"2^{a.logn}-point {a.curve.capitalize()} MSM per GPU, {a.scalars} 255-bit scalars, "
                                    f"resident key (BASELINE.json configs[1])",
-                       "points_per_gpu": n, "total_points": n * a.gpus, "window_bits": plan["window_bits"],
+                       "points_per_gpu": n, "total_points": n * (1 if by_windows else a.gpus), "window_bits": plan["window_bits"],
                        "windows": plan["windows"], "bucket_groups": plan["bucket_groups"], "tables": plan["tables"],
-                       "streams": nctx, "sharding": "points" if a.gpus > 1 else "none",
+                       "streams": nctx, "sharding": ("windows (w = rank mod N)" if by_windows else "points") if a.gpus > 1 else "none",
                        "exchange": ("none" if a.gpus == 1 else "rccl all_gather of 96 B partials + on-device add" if a.backend == "nccl"
                                     else "HOST-STAGED gloo all_gather of 96 B partials (debug fallback, not RCCL) + on-device add"),
                        "check": check, "msm_ms_stream": tot_ms},

@@ -228,6 +228,12 @@ reef_status reef_memcpy(void *dst, const void *src, size_t bytes, int dst_loc, i
 const char *reef_last_error(void);                     /* thread-local message of the last failure */
 const char *reef_version(void);
 
+/* One MSM split by Pippenger window across `world` GPUs (north_star): every GPU holds
+ * the whole key and receives all scalars, but accumulates only the windows w = rank (mod world), so
+ * reef_msm / reef_msm_rows on this ctx return a PARTIAL sum; the N partial sums (96 B each) are
+ * exchanged (RCCL all-gather) and added (reef_msm_ctx_sum_points).  world = 1 restores whole MSMs.
+ * Clones made afterwards inherit the setting. */
+reef_status reef_msm_ctx_set_window_split(reef_msm_ctx *ctx, uint32_t rank, uint32_t world);
 /* Per-MSM HIP-event timing is opt-in (each event record costs ~6 us of stream time). */
 reef_status reef_msm_ctx_enable_timing(reef_msm_ctx *ctx, int on);
 /* Timing of the last reef_msm / reef_msm_rows on this ctx, measured with HIP events on the ctx's

@@ -82,6 +82,7 @@ def load() -> ctypes.CDLL:
         "reef_version": (c_char_p, []),
         "reef_msm_ctx_last_timing": (c_int, [vp, POINTER(c_float), POINTER(c_float)]),
         "reef_msm_ctx_enable_timing": (c_int, [vp, c_int]),
+        "reef_msm_ctx_set_window_split": (c_int, [vp, c_uint32, c_uint32]),
         "reef_msm_ctx_timing_stats": (c_int, [vp, c_int, POINTER(c_uint64), POINTER(c_double), POINTER(c_double)]),
         "reef_msm_ctx_sum_points": (c_int, [vp, vp, c_size_t, vp]),
         "reef_msm_ctx_plan": (c_int, [vp, POINTER(c_uint32), POINTER(c_uint32), POINTER(c_uint32), POINTER(c_uint32)]),

@@ -133,6 +133,10 @@ reef_status reef_msm_ctx_last_timing(reef_msm_ctx *ctx, float *total_ms, float *
     if (!ctx) { set_error("null argument"); return REEF_ERR_ARG; }
     return vt(ctx->curve)->ctx_timing(ctx->impl, total_ms, accumulate_ms);
 }
+reef_status reef_msm_ctx_set_window_split(reef_msm_ctx *ctx, uint32_t rank, uint32_t world) {
+    if (!ctx) { set_error("null argument"); return REEF_ERR_ARG; }
+    return vt(ctx->curve)->ctx_window_split(ctx->impl, rank, world);
+}
 reef_status reef_msm_ctx_enable_timing(reef_msm_ctx *ctx, int on) {
     if (!ctx) { set_error("null argument"); return REEF_ERR_ARG; }
     return vt(ctx->curve)->ctx_enable_timing(ctx->impl, on);

@@ -55,6 +55,7 @@ struct CurveVTable {
     void *(*ctx_stream)(void *impl);
     reef_status (*ctx_timing)(void *impl, float *total_ms, float *acc_ms);
     reef_status (*ctx_enable_timing)(void *impl, int on);
+    reef_status (*ctx_window_split)(void *impl, uint32_t rank, uint32_t world);
     reef_status (*ctx_timing_stats)(void *impl, int reset, uint64_t *calls, double *total_ms, double *acc_ms);
     reef_status (*ctx_sum_points)(void *impl, const reef_jacobian *in, size_t n, reef_jacobian *out);
     reef_status (*ctx_plan)(void *impl, uint32_t *c, uint32_t *w, uint32_t *g, uint32_t *t);

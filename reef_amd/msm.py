@@ -148,6 +148,10 @@ class MsmContext:
         check(self._lib.reef_msm_ctx_plan(self._h, ctypes.byref(c), ctypes.byref(w), ctypes.byref(g), ctypes.byref(t)))
         return {"window_bits": c.value, "windows": w.value, "bucket_groups": g.value, "tables": t.value}
 
+    def set_window_split(self, rank: int, world: int) -> None:
+        """This context accumulates only the windows w = rank (mod world): its MSMs return partial sums."""
+        check(self._lib.reef_msm_ctx_set_window_split(self._h, rank, world))
+
     def enable_timing(self, on: bool = True) -> None:
         """HIP-event timing of every MSM on this context (off by default: ~6 us per event)."""
         check(self._lib.reef_msm_ctx_enable_timing(self._h, int(on)))

@@ -384,6 +384,39 @@ def test_rows_baseline_size_dlog_property(rows, row_len, bound, gpu_lib):
         assert comp[32 * r:32 * r + 32] == C.compress(C.mul(acc, C.gen)), r
 
 
+@pytest.mark.parametrize("groups,world", [(1, 2), (1, 8), (0, 3), (4, 4)])
+def test_window_split_partials_sum_to_the_msm(groups, world, gpu_lib, cref):
+    """One MSM split by Pippenger window over `world` devices (north_star): here the ranks
+    run one after the other on the same GPU; the partial sums must add up to the whole MSM, for
+    pre-shifted and plain keys, single MSMs and rows."""
+    from reef_amd import msm
+    cid = 0
+    n = 3000
+    bases = cref.gen_bases_ap(cid, 9, 2, n)
+    sc = cref.gen_scalars(cid, 1234, n, kind=0)
+    want = cref.compress(cid, cref.msm_pippenger(cid, bases, sc, threads=4))
+    rows, row_len = 3, 1000
+    want_rows = cref.compress(cid, cref.row_msm(cid, bases[:row_len].copy(), sc, rows, row_len, threads=4))
+    with msm.MsmContext(cid, bases, bucket_groups=groups) as ctx:
+        parts, row_parts = [], []
+        for r in range(world):
+            ctx.set_window_split(r, world)
+            c2 = ctx.clone()                                   # clones inherit the split
+            parts.append(c2.msm(sc))
+            row_parts.append(ctx.msm_rows(sc, rows, row_len))
+            c2.close()
+        total = msm.sum_points(cid, np.stack(parts))
+        assert msm.compress(cid, total) == want
+        got_rows = b"".join(msm.compress(cid, msm.sum_points(cid, np.stack([rp[i] for rp in row_parts]))) for i in range(rows))
+        assert got_rows == want_rows
+        if world > 1:
+            assert msm.compress(cid, parts[0]) != want          # a partial sum, not the MSM
+        ctx.set_window_split(0, 1)
+        assert msm.compress(cid, ctx.msm(sc)) == want
+        with pytest.raises(msm.ReefError):
+            ctx.set_window_split(2, 2)
+
+
 def test_bench_collective_path_on_one_gpu(gpu_lib):
     """bench.py's N > 1 code path (RCCL all_gather of the 96-byte partial sums on the MSM's own HIP
     stream + on-device combine) with a process group of one rank, small size: the JSON line must
