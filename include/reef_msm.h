@@ -114,6 +114,18 @@ reef_status reef_msm_rows(reef_msm_ctx *ctx, const reef_fe *scalars, size_t rows
                           const reef_fe *blinds, const reef_affine *h, reef_jacobian *out,
                           int out_loc);
 
+/* The same commitments from the document's own symbols: one unsigned byte per entry (< 2^symbol_bits,
+ * symbol_bits in 1..8), as Reef holds the document before turning it into field elements
+ * (src/backend/framework.rs:978-1011 -> NLDocCommitment::new, src/backend/commitment.rs:133-212).
+ * Tiny scalars need no bucket method: the generators are taken k at a time (2^(symbol_bits*k) <= 512),
+ * every combination is tabulated once per (ctx, row_len, symbol_bits), and a row is the plain sum of
+ * row_len/k table entries.  reef_msm_rows takes the same path on its own when max_scalar_bits <= 8 and
+ * the batch is large enough to pay for the tables.  blinds/h live where the symbols live; blinds are
+ * field elements (Montgomery form if blinds_are_mont). */
+reef_status reef_msm_rows_symbols(reef_msm_ctx *ctx, const uint8_t *symbols, size_t rows, size_t row_len, int symbols_loc,
+                                  uint32_t symbol_bits, const reef_fe *blinds, const reef_affine *h, bool blinds_are_mont,
+                                  reef_jacobian *out, int out_loc);
+
 /* IPA round WITHOUT generator folding.  After k rounds of G'_i = w1*G_i + w2*G_{i+half} the
  * generators are fixed linear combinations of the original ones, so the cross terms of round k
  *     L = <a_lo, G^(k)_hi>,   R = <a_hi, G^(k)_lo>        (a = a_lo || a_hi, n_k = n / 2^k scalars)

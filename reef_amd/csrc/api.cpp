@@ -170,6 +170,11 @@ reef_status reef_msm_plan_for(size_t n, uint32_t window_bits, uint32_t bucket_gr
     return pallas_vtable()->plan_for(n, window_bits, bucket_groups, c, windows, groups, tables);
 }
 
+reef_status reef_msm_rows_symbols(reef_msm_ctx *ctx, const uint8_t *symbols, size_t rows, size_t row_len, int loc, uint32_t symbol_bits,
+                                  const reef_fe *blinds, const reef_affine *h, bool blinds_are_mont, reef_jacobian *out, int out_loc) {
+    if (!ctx) { set_error("null argument"); return REEF_ERR_ARG; }
+    return vt(ctx->curve)->msm_rows_symbols(ctx->impl, symbols, rows, row_len, loc, symbol_bits, blinds, h, blinds_are_mont, out, out_loc);
+}
 reef_status reef_ipa_cross_terms(reef_msm_ctx *ctx, const reef_fe *a, size_t n_k, int a_loc, bool is_mont, const reef_fe *w1s,
                                  const reef_fe *w2s, size_t k, reef_jacobian *out_l, reef_jacobian *out_r) {
     if (!ctx) { set_error("null argument"); return REEF_ERR_ARG; }

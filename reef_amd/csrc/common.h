@@ -62,6 +62,8 @@ struct CurveVTable {
     reef_status (*msm)(void *impl, const reef_fe *scalars, size_t n, int loc, bool is_mont, reef_jacobian *out, int out_loc);
     reef_status (*msm_rows)(void *impl, const reef_fe *scalars, size_t rows, size_t row_len, int loc, bool is_mont,
                             uint32_t max_bits, const reef_fe *blinds, const reef_affine *h, reef_jacobian *out, int out_loc);
+    reef_status (*msm_rows_symbols)(void *impl, const uint8_t *symbols, size_t rows, size_t row_len, int loc, uint32_t bits,
+                                    const reef_fe *blinds, const reef_affine *h, bool blinds_are_mont, reef_jacobian *out, int out_loc);
     reef_status (*ipa_cross)(void *impl, const reef_fe *a, size_t n_k, int loc, bool is_mont, const reef_fe *w1s, const reef_fe *w2s, size_t k,
                              reef_jacobian *out_l, reef_jacobian *out_r);
     reef_status (*fold)(const reef_affine *gens, size_t half, int loc, const reef_fe *w1, const reef_fe *w2, reef_affine *out);

@@ -193,6 +193,26 @@ class MsmContext:
         check(self._lib.reef_msm(self._h, ptr, n, loc, bool(is_mont), optr, oloc))
         return out
 
+    def msm_rows_symbols(self, symbols: Buf, rows: int, row_len: int, symbol_bits: int, *, blinds: Optional[Buf] = None,
+                         h: Optional[Buf] = None, blinds_are_mont: bool = True, out: Optional[Buf] = None) -> Buf:
+        """HyraxPC::commit on one-byte document symbols (< 2^symbol_bits): uint8 array or device buffer of rows*row_len bytes."""
+        if isinstance(symbols, np.ndarray) and symbols.dtype != np.uint8:
+            raise TypeError("symbols must be uint8")
+        loc, ptr = _loc_ptr(symbols, rows * row_len)
+        bp = hp = None
+        if blinds is not None:
+            if h is None:
+                raise ValueError("blinds need the blinding generator h")
+            bloc, bp = _loc_ptr(blinds, 32 * rows)
+            hloc, hp = _loc_ptr(h, 64)
+            if bloc != loc or hloc != loc:
+                raise ValueError("blinds and h must live where the symbols live")
+        if out is None:
+            out = np.zeros((rows, 12), dtype=np.uint64)
+        oloc, optr = _loc_ptr(out, 96 * rows)
+        check(self._lib.reef_msm_rows_symbols(self._h, ptr, rows, row_len, loc, symbol_bits, bp, hp, bool(blinds_are_mont), optr, oloc))
+        return out
+
     def ipa_cross_terms(self, a: np.ndarray, w1s, w2s, *, is_mont: bool = True):
         """Cross terms (L, R) of IPA round k = len(w1s) over the original generators, without
         folding them: a = a_lo || a_hi (n / 2^k scalars), w1s/w2s = challenges so far (ints)."""

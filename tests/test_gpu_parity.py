@@ -326,6 +326,40 @@ def test_long_rows_batched_slice_sort(name, rows, row_len, groups, kind, gpu_lib
         assert msm.compress(cid, ctx.msm_rows(sc, rows, row_len, blinds=bl, h=h, max_scalar_bits=255)) == exp
 
 
+@pytest.mark.parametrize("name,rows,row_len,bound", [("pallas", 700, 300, 7), ("pallas", 1200, 200, 131), ("vesta", 900, 257, 4),
+                                                      ("pallas", 600, 1000, 16), ("pallas", 300, 2048, 2), ("vesta", 2500, 100, 256)])
+def test_rows_symbol_tables_vs_c_oracle(name, rows, row_len, bound, gpu_lib, cref):
+    """Document symbols through the block tables (no bucket method): large enough batches that
+    reef_msm_rows takes that path itself, and the same commitments from one-byte symbols
+    (reef_msm_rows_symbols); row lengths that are not multiples of the block size; with blinds."""
+    from reef_amd import msm
+    cid = CID[name]
+    bases = cref.gen_bases_ap(cid, 61, 17, row_len)
+    sc = cref.gen_scalars(cid, 2718, rows * row_len, kind=2, small_bound=bound)
+    canon = cref.gen_scalars(cid, 2718, rows * row_len, kind=2, small_bound=bound, mont=False)
+    sym = np.ascontiguousarray(canon[:, 0].astype(np.uint8))
+    assert int(canon[:, 0].max()) < bound and not canon[:, 1:].any()
+    bl = cref.gen_scalars(cid, 6, rows)
+    h = cref.gen_bases_ap(cid, 0xB11D, 1, 1)[0].copy()
+    exp = cref.compress(cid, cref.row_msm(cid, bases, sc, rows, row_len, h=h, blinds=bl, threads=8))
+    exp_nb = cref.compress(cid, cref.row_msm(cid, bases, sc, rows, row_len, threads=8))
+    bits = max(1, (bound - 1).bit_length())
+    with msm.MsmContext(cid, bases) as ctx:
+        assert msm.compress(cid, ctx.msm_rows(sc, rows, row_len, blinds=bl, h=h)) == exp                 # width measured on the device
+        assert msm.compress(cid, ctx.msm_rows(sc, rows, row_len, max_scalar_bits=bits)) == exp_nb        # cached tables
+        assert msm.compress(cid, ctx.msm_rows_symbols(sym, rows, row_len, bits, blinds=bl, h=h)) == exp
+        if bits < 8:                                                                                   # a wider declared width: other tables
+            assert msm.compress(cid, ctx.msm_rows_symbols(sym, rows, row_len, bits + 1)) == exp_nb
+        dsym = msm.DeviceBuffer.from_host(sym)
+        dout = msm.DeviceBuffer(96 * rows)
+        ctx.msm_rows_symbols(dsym, rows, row_len, bits, out=dout)
+        ctx.sync()
+        assert msm.compress(cid, dout.to_host((rows, 12))) == exp_nb
+        assert msm.compress(cid, ctx.msm_rows_symbols(sym[:row_len], 1, row_len, bits)) == exp_nb[:32]   # a single row
+        with pytest.raises(msm.ReefError):
+            ctx.msm_rows_symbols(sym, rows, row_len, 9)
+
+
 def test_fold_golden_and_oracle(golden, gpu_lib, cref):
     from reef_amd import msm
     for case in golden["fold"]:
