@@ -167,6 +167,23 @@ class HyraxPC:
         comp = msm.normalize(self.gens_v.curve, out, affine=False, compressed=True)[1]
         return out, comp
 
+    def commit_symbols(self, symbols: np.ndarray, blinds: np.ndarray, symbol_bits: int, *, blinds_are_mont: bool = True):
+        """HyraxPC::commit from the document symbols themselves (uint8, < 2^symbol_bits; the values Reef turns into
+        the polynomial's evaluations, framework.rs:978-1011): same row commitments as `commit`."""
+        symbols = np.ascontiguousarray(symbols, dtype=np.uint8).reshape(-1)
+        n = symbols.shape[0]
+        if n & (n - 1):
+            raise ValueError("polynomial length must be a power of two")
+        left, right = self.compute_factored_lens(n.bit_length() - 1)
+        rows, row_len = 1 << left, 1 << right
+        if row_len > len(self.gens_v):
+            raise ValueError("not enough row generators")
+        blinds = np.ascontiguousarray(blinds, dtype=np.uint64).reshape(rows, 4)
+        out = self.gens_v._context().msm_rows_symbols(symbols, rows, row_len, symbol_bits, blinds=blinds, h=self.gens_v.h,
+                                                      blinds_are_mont=blinds_are_mont)
+        comp = msm.normalize(self.gens_v.curve, out, affine=False, compressed=True)[1]
+        return out, comp
+
     def bind_rows(self, poly, blinds: np.ndarray, point: np.ndarray, *, is_mont: bool = True, n=None, elem_bytes=None):
         """First step of HyraxPC::prove_eval (src/backend/commitment.rs:371-391): with (L, R) the
         eq-evaluations of the two halves of `point`, returns (LZ = L^T Z, eval = <LZ, R>,
