@@ -76,7 +76,7 @@ typedef struct {
                                (all windows share one bucket set); otherwise windows w and w'
                                share buckets iff w % G == w' % G */
     uint32_t chunk;         /* sorted entries per accumulation thread (L0); 0 = default */
-    uint32_t segment;       /* reserved (was: buckets per bucket-reduce thread); must be 0 or a power of two */
+    uint32_t segment;       /* reserved, ignored */
     int32_t device;         /* HIP device ordinal; -1 = current device */
     uint32_t reserved[3];
 } reef_msm_opts;
