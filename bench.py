@@ -40,7 +40,6 @@ def parse():
     p.add_argument("--window-bits", type=int, default=0)
     p.add_argument("--bucket-groups", type=int, default=-1, help="-1: engine default for the bench key")
     p.add_argument("--chunk", type=int, default=0)
-    p.add_argument("--segment", type=int, default=0)
     p.add_argument("--streams", type=int, default=3, help="MSMs in flight (clones of the key on separate HIP streams)")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--cpu-seconds", type=float, default=12.0)
@@ -143,7 +142,7 @@ def main():
     # synthetic inputs, generated on the device: rank r owns bases B_i, i in [r*n, (r+1)*n)
     bases = msm.gen_bases(a.curve, k0 + owner * n * d, d, n, device=True)
     scalars = msm.gen_scalars(a.curve, seed, n, kind=kind, mont=True, device=True)
-    ctx0 = msm.MsmContext(a.curve, bases, n, window_bits=a.window_bits, bucket_groups=groups, chunk=a.chunk, segment=a.segment)
+    ctx0 = msm.MsmContext(a.curve, bases, n, window_bits=a.window_bits, bucket_groups=groups, chunk=a.chunk)
     if by_windows:
         ctx0.set_window_split(rank, max(world, 1))
     ctxs = [ctx0] + [ctx0.clone() for _ in range(max(1, a.streams) - 1)]

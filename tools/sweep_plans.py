@@ -5,13 +5,13 @@ import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from reef_amd import msm
 
-def run(logn, c, g, kind=0, reps=6, chunk=0, seg=0):
+def run(logn, c, g, kind=0, reps=6, chunk=0):
     n = 1 << logn
     bases = msm.gen_bases("pallas", 12345, 7, n, device=True)
     sc = msm.gen_scalars("pallas", 99, n, kind=kind, device=True)
     out = msm.DeviceBuffer(96)
     try:
-        ctx = msm.MsmContext("pallas", bases, n, window_bits=c, bucket_groups=g, chunk=chunk, segment=seg)
+        ctx = msm.MsmContext("pallas", bases, n, window_bits=c, bucket_groups=g, chunk=chunk)
     except msm.ReefError as e:
         return None
     ctx.enable_timing(True)
