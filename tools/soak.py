@@ -1,0 +1,66 @@
+#!/usr/bin/env python3
+"""Randomised soak of the C ABI against the oracle's C restatement: sizes, curves, scalar shapes, key kinds,
+rows and symbol commits, window splits.  Usage: python tools/soak.py [seconds] [seed]"""
+import os
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from oracle import pasta_ref as R  # noqa: E402
+from reef_amd import msm  # noqa: E402
+
+budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+t_end = time.time() + budget
+done = 0
+while time.time() < t_end:
+    cid = int(rng.integers(0, 2))
+    shape = rng.integers(0, 4)
+    if shape == 0:      # single MSM, any size
+        n = int(2 ** rng.uniform(0, 18.5))
+        kind = int(rng.integers(0, 3))
+        bases = R.gen_bases_ap(cid, int(rng.integers(1, 1 << 30)), int(rng.integers(1, 1000)), n)
+        sc = R.gen_scalars(cid, int(rng.integers(1, 1 << 30)), n, kind=kind, small_bound=int(rng.integers(2, 70000)))
+        if n > 8 and rng.random() < 0.3:
+            bases[rng.integers(0, n, size=3)] = 0
+            sc[rng.integers(0, n, size=3)] = 0
+        want = R.compress(cid, R.msm_pippenger(cid, bases, sc, threads=16))
+        groups = int(rng.choice([0, 1, 1, 3]))
+        with msm.MsmContext(cid, bases, bucket_groups=groups, window_bits=int(rng.choice([0, 0, 7, 13, 15, 16]))) as ctx:
+            m = int(rng.integers(1, n + 1)) if rng.random() < 0.3 else n
+            got = msm.compress(cid, ctx.msm(sc[:m].copy()))
+            if m != n:
+                want = R.compress(cid, R.msm_pippenger(cid, bases[:m].copy(), sc[:m].copy(), threads=16))
+            assert got == want, ("msm", cid, n, m, kind, groups)
+            if rng.random() < 0.3:
+                world = int(rng.integers(2, 9))
+                parts = []
+                for r in range(world):
+                    ctx.set_window_split(r, world)
+                    parts.append(ctx.msm(sc[:m].copy()))
+                ctx.set_window_split(0, 1)
+                assert msm.compress(cid, msm.sum_points(cid, np.stack(parts))) == want, ("split", cid, n, m, world)
+    elif shape == 1:    # stateless drop-in symbol
+        n = int(2 ** rng.uniform(0, 16))
+        bases = R.gen_bases_ap(cid, int(rng.integers(1, 1 << 30)), 3, n)
+        sc = R.gen_scalars(cid, int(rng.integers(1, 1 << 30)), n, kind=int(rng.integers(0, 2)))
+        assert msm.compress(cid, msm.mult_pippenger(cid, bases, sc)) == R.compress(cid, R.msm_pippenger(cid, bases, sc, threads=16)), ("pip", cid, n)
+    else:               # rows (field elements and symbols)
+        rows, row_len = int(2 ** rng.uniform(0, 11)), int(2 ** rng.uniform(0, 12))
+        bound = int(rng.choice([2, 4, 7, 16, 131, 256, 1 << 16, 0]))
+        bases = R.gen_bases_ap(cid, int(rng.integers(1, 1 << 30)), 5, row_len)
+        seed = int(rng.integers(1, 1 << 30))
+        sc = R.gen_scalars(cid, seed, rows * row_len, kind=2 if bound else 0, small_bound=bound)
+        bl = R.gen_scalars(cid, seed + 1, rows)
+        h = R.gen_bases_ap(cid, 0xB11D, 1, 1)[0].copy()
+        want = R.compress(cid, R.row_msm(cid, bases, sc, rows, row_len, h=h, blinds=bl, threads=16))
+        with msm.MsmContext(cid, bases, bucket_groups=int(rng.choice([0, 1]))) as ctx:
+            assert msm.compress(cid, ctx.msm_rows(sc, rows, row_len, blinds=bl, h=h)) == want, ("rows", cid, rows, row_len, bound)
+            if 0 < bound <= 256:
+                sym = np.ascontiguousarray(R.gen_scalars(cid, seed, rows * row_len, kind=2, small_bound=bound, mont=False)[:, 0].astype(np.uint8))
+                bits = max(1, (bound - 1).bit_length())
+                assert msm.compress(cid, ctx.msm_rows_symbols(sym, rows, row_len, bits, blinds=bl, h=h)) == want, ("sym", cid, rows, row_len, bound)
+    done += 1
+print(f"soak ok: {done} random cases in {budget:.0f} s")
