@@ -55,6 +55,9 @@ typedef enum {
  * Stateless: nothing is retained; bases are uploaded per call.  `is_mont` = scalars are in
  * Montgomery form (what the Rust wrapper passes).  abort()s on error.
  * ------------------------------------------------------------------------------------------- */
+/* (A key that keeps coming back is recognised by a fingerprint of its uploaded bytes and, from its third
+ * call on, served from a resident pre-shifted copy; nothing the caller can observe is retained.
+ * REEF_MSM_KEY_CACHE=0 in the environment turns this off.) */
 void mult_pippenger_pallas(reef_jacobian *out, const reef_affine *points, size_t npoints,
                            const reef_fe *scalars, bool is_mont);
 void mult_pippenger_vesta(reef_jacobian *out, const reef_affine *points, size_t npoints,

@@ -2,6 +2,7 @@
 // no arithmetic here and no CPU fallback: without a gfx950 device every call fails loudly.
 #include <stdarg.h>
 #include <stdio.h>
+#include <vector>
 #include <stdlib.h>
 #include <string.h>
 
@@ -284,24 +285,87 @@ reef_status reef_sc_sync(reef_sc_ctx *ctx) {
 // A per-thread context is kept so that repeated calls reuse the workspace; the bases are
 // re-uploaded on every call, as the reference semantics (nothing retained) require.
 namespace {
+// A commitment key that keeps coming back (Reef commits to the same generators in every folding step,
+// src/backend/framework.rs:297-303) is recognised by the fingerprint of its uploaded bytes; from its
+// third appearance on the call runs on a resident pre-shifted copy (the bases still cross PCIe, but
+// import, the plain-key pipeline and the host-side window combine are skipped).  Keys seen once -- the
+// folded generators of an IPA round -- never get a resident copy.  REEF_MSM_KEY_CACHE=0 turns it off.
+struct KeyCacheEntry {
+    uint64_t h[2] = {0, 0};
+    size_t n = 0;
+    reef_msm_ctx *resident = nullptr;
+    uint64_t last_use = 0;
+};
 struct TlsCtx {
     reef_msm_ctx *ctx[2] = {nullptr, nullptr};
+    void *stage = nullptr;
+    size_t stage_cap = 0;
+    std::vector<KeyCacheEntry> cache[2];
+    uint64_t tick = 0;
     ~TlsCtx() {
         for (auto *c : ctx) reef_msm_ctx_destroy(c);
+        for (auto &v : cache)
+            for (auto &e : v) reef_msm_ctx_destroy(e.resident);
+        if (stage) reef_device_free(stage);
     }
 };
 thread_local TlsCtx g_tls;
+constexpr size_t KEY_CACHE_MIN_POINTS = 1024, KEY_CACHE_ENTRIES = 6;
+
+static reef_status pippenger_try(int curve, reef_jacobian *out, const reef_affine *points, size_t npoints, const reef_fe *scalars, bool is_mont) {
+    static const bool cache_on = !(getenv("REEF_MSM_KEY_CACHE") && atoi(getenv("REEF_MSM_KEY_CACHE")) == 0);
+    reef_msm_ctx *&c = g_tls.ctx[curve];
+    if (!cache_on || npoints < KEY_CACHE_MIN_POINTS) {
+        if (!c) REEF_TRY(reef_msm_ctx_create(&c, curve, points, npoints, REEF_HOST, nullptr));
+        else REEF_TRY(vt(curve)->ctx_rekey(c->impl, points, npoints, REEF_HOST));
+        return reef_msm(c, scalars, npoints, REEF_HOST, is_mont, out, REEF_HOST);
+    }
+    const size_t bytes = npoints * sizeof(reef_affine);
+    if (bytes > g_tls.stage_cap) {
+        if (g_tls.stage) reef_device_free(g_tls.stage);
+        g_tls.stage = reef_device_alloc(bytes + bytes / 8);
+        g_tls.stage_cap = g_tls.stage ? bytes + bytes / 8 : 0;
+        if (!g_tls.stage) return REEF_ERR_OOM;
+    }
+    REEF_TRY(reef_memcpy(g_tls.stage, points, bytes, REEF_DEVICE, REEF_HOST));
+    uint64_t h[2];
+    REEF_TRY(vt(curve)->fingerprint(g_tls.stage, bytes, h));
+    auto &cache = g_tls.cache[curve];
+    KeyCacheEntry *hit = nullptr;
+    for (auto &e : cache)
+        if (e.n == npoints && e.h[0] == h[0] && e.h[1] == h[1]) hit = &e;
+    const uint64_t now = ++g_tls.tick;
+    if (hit && hit->resident) {
+        hit->last_use = now;
+        return reef_msm(hit->resident, scalars, npoints, REEF_HOST, is_mont, out, REEF_HOST);
+    }
+    const reef_affine *staged = (const reef_affine *)g_tls.stage;
+    if (!c) REEF_TRY(reef_msm_ctx_create(&c, curve, staged, npoints, REEF_DEVICE, nullptr));
+    else REEF_TRY(vt(curve)->ctx_rekey(c->impl, staged, npoints, REEF_DEVICE));
+    REEF_TRY(reef_msm(c, scalars, npoints, REEF_HOST, is_mont, out, REEF_HOST));
+    if (hit) {                                         // second appearance: worth a resident pre-shifted copy
+        hit->last_use = now;
+        reef_msm_opts o = {};
+        o.bucket_groups = 1;
+        o.device = -1;
+        if (reef_msm_ctx_create(&hit->resident, curve, staged, npoints, REEF_DEVICE, &o) != REEF_OK) hit->resident = nullptr;
+        return REEF_OK;
+    }
+    if (cache.size() >= KEY_CACHE_ENTRIES) {           // forget the least recently used key
+        size_t lru = 0;
+        for (size_t i = 1; i < cache.size(); ++i)
+            if (cache[i].last_use < cache[lru].last_use) lru = i;
+        reef_msm_ctx_destroy(cache[lru].resident);
+        cache.erase(cache.begin() + lru);
+    }
+    KeyCacheEntry e;
+    e.h[0] = h[0]; e.h[1] = h[1]; e.n = npoints; e.last_use = now;
+    cache.push_back(e);
+    return REEF_OK;
+}
 
 static void pippenger(int curve, reef_jacobian *out, const reef_affine *points, size_t npoints, const reef_fe *scalars, bool is_mont) {
-    reef_status st;
-    reef_msm_ctx *&c = g_tls.ctx[curve];
-    if (!c) {
-        st = reef_msm_ctx_create(&c, curve, points, npoints, REEF_HOST, nullptr);
-    } else {
-        st = vt(curve)->ctx_rekey(c->impl, points, npoints, REEF_HOST);
-    }
-    if (st == REEF_OK) st = reef_msm(c, scalars, npoints, REEF_HOST, is_mont, out, REEF_HOST);
-    if (st != REEF_OK) {
+    if (pippenger_try(curve, out, points, npoints, scalars, is_mont) != REEF_OK) {
         fprintf(stderr, "libreef_msm: mult_pippenger_%s failed: %s\n", curve == REEF_PALLAS ? "pallas" : "vesta", reef_last_error());
         abort();
     }

@@ -199,6 +199,32 @@ def test_ragged_sizes_prefixes_and_holes(name, gpu_lib, cref):
             assert msm.compress(cid, ctx.msm(np.zeros((0, 4), dtype=np.uint64))) == bytes(32)   # empty MSM
 
 
+@pytest.mark.parametrize("name", ["pallas", "vesta"])
+def test_stateless_symbol_recognises_a_returning_key(name, gpu_lib, cref):
+    """The drop-in symbol retains nothing the caller can see, but a key that keeps coming back is served
+    from a resident pre-shifted copy from its third call on (fingerprint of the uploaded bytes).  Same
+    results on every call; a key edited in place (same pointer, same length) must not be mistaken
+    for the old one; more keys than cache slots still work."""
+    from reef_amd import msm
+    cid = CID[name]
+    n = 3000
+    bases = cref.gen_bases_ap(cid, 1001, 7, n)
+    for rep in range(5):                                          # 1st: plain, 2nd: plain + resident copy built, 3rd..: resident
+        sc = cref.gen_scalars(cid, 50 + rep, n, kind=rep % 2)
+        assert msm.compress(cid, msm.mult_pippenger(cid, bases, sc)) == cref.compress(cid, cref.msm_pippenger(cid, bases, sc, threads=4)), rep
+    sc = cref.gen_scalars(cid, 99, n)
+    bases[17] = cref.gen_bases_ap(cid, 5, 1, 1)[0]                # in-place edit of one point
+    want = cref.compress(cid, cref.msm_pippenger(cid, bases, sc, threads=4))
+    for rep in range(4):
+        assert msm.compress(cid, msm.mult_pippenger(cid, bases, sc)) == want, rep
+    keys = [cref.gen_bases_ap(cid, 2000 + 13 * k, 3, 1500) for k in range(9)]     # more keys than slots, revisited
+    sck = cref.gen_scalars(cid, 7, 1500)
+    wants = [cref.compress(cid, cref.msm_pippenger(cid, kb, sck, threads=4)) for kb in keys]
+    for rnd in range(3):
+        for kb, w in zip(keys, wants):
+            assert msm.compress(cid, msm.mult_pippenger(cid, kb, sck)) == w, rnd
+
+
 @pytest.mark.parametrize("name,logn,kind,groups", [("pallas", 20, 0, 0), ("pallas", 20, 1, 0), ("vesta", 18, 0, 0),
                                                    ("pallas", 18, 0, 1), ("vesta", 17, 1, 1)])
 def test_full_size_dlog_property(name, logn, kind, groups, gpu_lib):
