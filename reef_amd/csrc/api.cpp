@@ -352,9 +352,14 @@ static reef_status pippenger_try(int curve, reef_jacobian *out, const reef_affin
         return REEF_OK;
     }
     if (cache.size() >= KEY_CACHE_ENTRIES) {           // forget the least recently used key
-        size_t lru = 0;
-        for (size_t i = 1; i < cache.size(); ++i)
-            if (cache[i].last_use < cache[lru].last_use) lru = i;
+        size_t lru = cache.size();                      // keys seen once (no resident copy) go first
+        for (size_t i = 0; i < cache.size(); ++i)
+            if (!cache[i].resident && (lru == cache.size() || cache[i].last_use < cache[lru].last_use)) lru = i;
+        if (lru == cache.size()) {
+            lru = 0;
+            for (size_t i = 1; i < cache.size(); ++i)
+                if (cache[i].last_use < cache[lru].last_use) lru = i;
+        }
         reef_msm_ctx_destroy(cache[lru].resident);
         cache.erase(cache.begin() + lru);
     }
