@@ -19,7 +19,7 @@ while time.time() < t_end:
     cid = int(rng.integers(0, 2))
     shape = rng.integers(0, 4)
     if shape == 0:      # single MSM, any size
-        n = int(2 ** rng.uniform(0, 18.5))
+        n = int(2 ** rng.uniform(0, 21.2 if os.environ.get("SOAK_BIG") else 18.5))
         kind = int(rng.integers(0, 3))
         bases = R.gen_bases_ap(cid, int(rng.integers(1, 1 << 30)), int(rng.integers(1, 1000)), n)
         sc = R.gen_scalars(cid, int(rng.integers(1, 1 << 30)), n, kind=kind, small_bound=int(rng.integers(2, 70000)))
@@ -48,7 +48,8 @@ while time.time() < t_end:
         sc = R.gen_scalars(cid, int(rng.integers(1, 1 << 30)), n, kind=int(rng.integers(0, 2)))
         assert msm.compress(cid, msm.mult_pippenger(cid, bases, sc)) == R.compress(cid, R.msm_pippenger(cid, bases, sc, threads=16)), ("pip", cid, n)
     else:               # rows (field elements and symbols)
-        rows, row_len = int(2 ** rng.uniform(0, 11)), int(2 ** rng.uniform(0, 12))
+        big = 2 if os.environ.get("SOAK_BIG") else 0
+        rows, row_len = int(2 ** rng.uniform(0, 11 + big)), int(2 ** rng.uniform(0, 12 + big / 2))
         bound = int(rng.choice([2, 4, 7, 16, 131, 256, 1 << 16, 0]))
         bases = R.gen_bases_ap(cid, int(rng.integers(1, 1 << 30)), 5, row_len)
         seed = int(rng.integers(1, 1 << 30))
