@@ -247,6 +247,8 @@ const char *reef_version(void);
  * the whole key and receives all scalars, but accumulates only the windows w = rank (mod world), so
  * reef_msm / reef_msm_rows on this ctx return a PARTIAL sum; the N partial sums (96 B each) are
  * exchanged (RCCL all-gather) and added (reef_msm_ctx_sum_points).  world = 1 restores whole MSMs.
+ * A Pedersen blind term is added by rank 0 only, and row commitments that go through the symbol tables
+ * (no windows to split) are computed whole by rank 0, the other ranks returning the identity.
  * Clones made afterwards inherit the setting. */
 reef_status reef_msm_ctx_set_window_split(reef_msm_ctx *ctx, uint32_t rank, uint32_t world);
 /* Per-MSM HIP-event timing is opt-in (each event record costs ~6 us of stream time). */

@@ -456,19 +456,26 @@ def test_window_split_partials_sum_to_the_msm(groups, world, gpu_lib, cref):
     sc = cref.gen_scalars(cid, 1234, n, kind=0)
     want = cref.compress(cid, cref.msm_pippenger(cid, bases, sc, threads=4))
     rows, row_len = 3, 1000
-    want_rows = cref.compress(cid, cref.row_msm(cid, bases[:row_len].copy(), sc, rows, row_len, threads=4))
+    bl = cref.gen_scalars(cid, 77, rows)
+    h = cref.gen_bases_ap(cid, 0xB11D, 1, 1)[0].copy()
+    want_rows = cref.compress(cid, cref.row_msm(cid, bases[:row_len].copy(), sc, rows, row_len, h=h, blinds=bl, threads=4))   # the blind term once
+    small = cref.gen_scalars(cid, 3, 600 * 500, kind=2, small_bound=7)                       # large enough for the symbol tables
+    want_small = cref.compress(cid, cref.row_msm(cid, bases[:500].copy(), small, 600, 500, h=h, blinds=cref.gen_scalars(cid, 78, 600), threads=8))
     with msm.MsmContext(cid, bases, bucket_groups=groups) as ctx:
-        parts, row_parts = [], []
+        parts, row_parts, small_parts = [], [], []
         for r in range(world):
             ctx.set_window_split(r, world)
             c2 = ctx.clone()                                   # clones inherit the split
             parts.append(c2.msm(sc))
-            row_parts.append(ctx.msm_rows(sc, rows, row_len))
+            row_parts.append(ctx.msm_rows(sc, rows, row_len, blinds=bl, h=h))
+            small_parts.append(ctx.msm_rows(small, 600, 500, blinds=cref.gen_scalars(cid, 78, 600), h=h))
             c2.close()
         total = msm.sum_points(cid, np.stack(parts))
         assert msm.compress(cid, total) == want
         got_rows = b"".join(msm.compress(cid, msm.sum_points(cid, np.stack([rp[i] for rp in row_parts]))) for i in range(rows))
         assert got_rows == want_rows
+        got_small = b"".join(msm.compress(cid, msm.sum_points(cid, np.stack([sp[i] for sp in small_parts]))) for i in range(600))
+        assert got_small == want_small
         if world > 1:
             assert msm.compress(cid, parts[0]) != want          # a partial sum, not the MSM
         ctx.set_window_split(0, 1)
