@@ -337,7 +337,8 @@ def test_rows_vs_c_oracle(name, rows, row_len, bound, gpu_lib, cref):
 
 
 @pytest.mark.parametrize("name,rows,row_len,groups,kind", [("pallas", 3, 8192, 0, 0), ("vesta", 2, 9000, 1, 0),
-                                                          ("pallas", 5, 8200, 1, 1), ("pallas", 2, 16384, 4, 0)])
+                                                          ("pallas", 5, 8200, 1, 1), ("pallas", 2, 16384, 4, 0),
+                                                          ("pallas", 2, 65536, 1, 0), ("vesta", 3, 40000, 1, 1)])   # the last two: two-level sort
 def test_long_rows_batched_slice_sort(name, rows, row_len, groups, kind, gpu_lib, cref):
     """Rows of K1 size (>= 8192 wide scalars) go through the sliced sort as one batch of MSMs."""
     from reef_amd import msm
