@@ -117,6 +117,43 @@ def test_ipa_without_generator_folding(groups, gpu_lib, cref):
             w2s.append(w2)
 
 
+def test_ipa_cross_terms_at_prover_size_dlog_property(gpu_lib):
+    """The L/R batch at the size of Reef's final IPA (2^16 generators: the batch goes through the two-level
+    sort).  Generators in arithmetic progression, so a cross term is (sum_j s[j] * (k0 + j*d)) * G with the
+    expanded scalars of the definition: s_L[j] = a[i - n_k/2] * coef[t] on the upper half of block t,
+    s_R[j] = a[i + n_k/2] * coef[t] on the lower half, coef[t] = prod_m (bit_{k-1-m}(t) ? w2_m : w1_m)."""
+    from reef_amd import msm
+    C = CURVES["pallas"]
+    q = C.order
+    n, k0, d = 1 << 16, 424242, 77
+    gens = msm.gen_bases("pallas", k0, d, n)
+    rng = SplitMix64(2025)
+    a_canon = msm.gen_scalars("pallas", 31, n, mont=False)
+    a_int = [sum(int(a_canon[i, j]) << (64 * j) for j in range(4)) for i in range(n)]
+    with msm.MsmContext("pallas", gens, bucket_groups=1) as ctx:
+        w1s, w2s = [], []
+        for k in range(0, 4):
+            n_k, half = n >> k, n >> (k + 1)
+            coef = []
+            for t in range(1 << k):
+                c = 1
+                for m in range(k):
+                    c = c * (w2s[m] if (t >> (k - 1 - m)) & 1 else w1s[m]) % q
+                coef.append(c)
+            accl = accr = 0
+            for j in range(n):
+                i, t = j & (n_k - 1), j // n_k
+                if i >= half:
+                    accl += a_int[i - half] * coef[t] % q * (k0 + j * d)
+                else:
+                    accr += a_int[i + half] * coef[t] % q * (k0 + j * d)
+            L, R = ctx.ipa_cross_terms(np.ascontiguousarray(a_canon[:n_k]), w1s, w2s, is_mont=False)
+            assert msm.compress("pallas", L) == C.compress(C.mul(accl % q, C.gen)), k
+            assert msm.compress("pallas", R) == C.compress(C.mul(accr % q, C.gen)), k
+            w1s.append(uniform_scalar(rng, q))
+            w2s.append(uniform_scalar(rng, q))
+
+
 def test_hyrax_bind_rows_is_consistent_with_commit(gpu_lib, cref):
     """prove_eval's row binding (commitment.rs:371-391): commit(LZ; LZ_blind) must equal
     sum_i L_i * C_i over the row commitments -- the relation the Hyrax verifier checks."""
