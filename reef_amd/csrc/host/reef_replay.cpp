@@ -13,6 +13,8 @@
 //   final SNARK      one more |C2| MSM, then for each curve an IPA over the padded key length:
 //                    log2 N rounds of { L, R cross MSMs (issued on two streams), generator fold }
 //   consistency      IPA of the Hyrax row length (prove_eval, commitment.rs:371/383)
+// and, beside the MSMs: the Hyrax commitment of the document (--commit), one nlookup sum-check per
+// folding step (rows N2) and the document polynomial's row binding at proof end (row N3).
 // Build: g++ -O2 -std=c++17 reef_replay.cpp -I../../../include -L../../_lib -lreef_msm -o reef_replay
 #include <chrono>
 #include <cstdio>
@@ -37,13 +39,17 @@ struct Shape {
     size_t w1, c1, w2, c2;   // |W1|, |C1| (Pallas), |W2|, |C2| (Vesta)
     int steps;
     size_t hyrax_row;        // R = 2^(l - l/2): length of the consistency IPA (0 = merkle mode)
+    int doc_log;             // l = log2 of the padded document length the Hyrax commitment covers (0: no Hyrax commitment)
+    int symbol_bits;         // width of a document symbol (alphabet + EOF/EPSILON, framework.rs:978-1011)
+    int table_log;           // log2 of the table the per-step nlookup sum-check runs over (r1cs.rs:2318-2385); 0: not replayed
+    int lookups;             // lookups folded per step (batch size)
 };
 // BASELINE.json configs as sized in SURVEY.md 8 (predictions of costs.rs, not measurements)
 static const Shape SHAPES[] = {
-    {"cfg1_9B_ascii", 17000, 16700, 11400, 11376, 3, 4},
-    {"cfg3_1MiB_ascii_password", 26000, 26000, 11400, 11376, 3, 2048},
-    {"cfg4_16MiB_dna_hybrid_b32", 39000, 39000, 11400, 11376, 4, 8192},
-    {"cfg5_64MiB_utf8_merkle", 65000, 65000, 11400, 11376, 4, 0},
+    {"cfg1_9B_ascii", 17000, 16700, 11400, 11376, 3, 4, 4, 8, 10, 4},
+    {"cfg3_1MiB_ascii_password", 26000, 26000, 11400, 11376, 3, 2048, 21, 8, 21, 16},
+    {"cfg4_16MiB_dna_hybrid_b32", 39000, 39000, 11400, 11376, 4, 8192, 25, 3, 26, 32},
+    {"cfg5_64MiB_utf8_merkle", 65000, 65000, 11400, 11376, 4, 0, 0, 8, 0, 32},
 };
 
 struct Curve {
@@ -107,6 +113,65 @@ static double run_ipa(Curve &c, size_t n, const reef_fe *d_scalars, int *rounds_
     reef_device_free(buf[0]);
     reef_device_free(buf[1]);
     if (rounds_out) *rounds_out = rounds;
+    return ms_since(t0);
+}
+
+// ---- the work around the MSMs that this backend also covers -------------------------------------
+// --commit: HyraxPC::commit over the document matrix (commitment.rs:187), from the document bytes.
+// per step: the nlookup sum-check of witness generation (r1cs.rs:2318-2385) as reef_sc_* rounds, the
+//           Poseidon challenge of every round replaced by a fixed field element (it stays on the host).
+// proof end: doc_poly.evaluate / the row binding of prove_eval (commitment.rs:357,371-391).
+static uint8_t *device_symbols(size_t n, int bits, uint64_t seed) {
+    std::vector<uint8_t> h(n);
+    uint64_t x = seed;
+    const uint32_t bound = bits >= 8 ? 131u : (bits == 3 ? 7u : (1u << bits));
+    for (size_t i = 0; i < n; ++i) {
+        x = x * 6364136223846793005ULL + 1442695040888963407ULL;
+        h[i] = (uint8_t)((x >> 33) % bound);
+    }
+    uint8_t *d = (uint8_t *)reef_device_alloc(n);
+    if (!d) { fprintf(stderr, "alloc: %s\n", reef_last_error()); exit(1); }
+    CK(reef_memcpy(d, h.data(), n, REEF_DEVICE, REEF_HOST));
+    return d;
+}
+
+static double run_hyrax_commit(const Shape *sh, reef_affine *d_gens, const uint8_t *d_doc, double *first_ms) {
+    const size_t rows = (size_t)1 << (sh->doc_log / 2), row_len = (size_t)1 << (sh->doc_log - sh->doc_log / 2);
+    reef_msm_ctx *key = nullptr;
+    CK(reef_msm_ctx_create(&key, REEF_PALLAS, d_gens, row_len, REEF_DEVICE, nullptr));
+    reef_jacobian *d_out = (reef_jacobian *)reef_device_alloc(rows * sizeof(reef_jacobian));
+    auto t0 = clk::now();
+    CK(reef_msm_rows_symbols(key, d_doc, rows, row_len, REEF_DEVICE, (uint32_t)sh->symbol_bits, nullptr, nullptr, true, d_out, REEF_DEVICE));
+    CK(reef_msm_ctx_sync(key));
+    *first_ms = ms_since(t0);                          // includes the construction of the symbol tables
+    t0 = clk::now();
+    CK(reef_msm_rows_symbols(key, d_doc, rows, row_len, REEF_DEVICE, (uint32_t)sh->symbol_bits, nullptr, nullptr, true, d_out, REEF_DEVICE));
+    CK(reef_msm_ctx_sync(key));
+    const double again = ms_since(t0);
+    reef_device_free(d_out);
+    reef_msm_ctx_destroy(key);
+    return again;
+}
+
+static double run_sumcheck_step(reef_sc_ctx *sc, int ell, int lookups) {
+    std::vector<reef_fe> rs(lookups + 1), last_q(ell);
+    std::vector<uint32_t> qs(lookups);
+    for (int i = 0; i <= lookups; ++i) rs[i] = reef_fe{{0x9e3779b97f4a7c15ULL * (i + 1), 0x1234ULL + i, 0, 0}};
+    for (int i = 0; i < lookups; ++i) qs[i] = (uint32_t)((0x2545F4914F6CDD1DULL * (i + 7)) >> (64 - ell));
+    for (int j = 0; j < ell; ++j) last_q[j] = reef_fe{{0xabcdef12345ULL + j, 0x77ULL * j, 0, 0}};
+    auto t0 = clk::now();
+    CK(reef_sc_reset_table(sc));
+    CK(reef_sc_gen_eq_table(sc, rs.data(), qs.data(), lookups, last_q.data(), ell));
+    reef_fe g[3];
+    CK(reef_sc_round_coeffs(sc, (size_t)1 << (ell - 1), g));
+    for (int i = 1; i <= ell; ++i) {
+        const reef_fe r = {{0x5851f42d4c957f2dULL + i, 0x14057b7ef767814fULL, 0x0123456789abcdefULL, 0x0fedcba987654321ULL}};
+        const size_t pow = (size_t)1 << (ell - i);
+        if (pow >= 2) CK(reef_sc_fold_and_next_coeffs(sc, pow, &r, g));
+        else CK(reef_sc_fold(sc, pow, &r));
+    }
+    reef_fe v;
+    CK(reef_sc_read(sc, 0, 1, &v));                    // next_running_v (r1cs.rs:2379-2385)
     return ms_since(t0);
 }
 
@@ -199,13 +264,49 @@ int main(int argc, char **argv) {
         }
     }
 
+    // ---- commitment of the document, the per-step sum-check and the document polynomial at proof end
+    double commit_ms = 0, commit_first_ms = 0, sc_step_ms = 0, mle_ms = 0;
+    if (sh->doc_log) {
+        const size_t n_doc = (size_t)1 << sh->doc_log;
+        uint8_t *d_doc = device_symbols(n_doc, sh->symbol_bits, 0xD0C);
+        const size_t row_len = (size_t)1 << (sh->doc_log - sh->doc_log / 2);
+        reef_affine *d_row_gens = (reef_affine *)reef_device_alloc(row_len * sizeof(reef_affine));
+        CK(reef_gen_bases(REEF_PALLAS, 0xFEED, 3, row_len, d_row_gens, REEF_DEVICE));
+        commit_ms = run_hyrax_commit(sh, d_row_gens, d_doc, &commit_first_ms);
+        std::vector<reef_fe> point(sh->doc_log);
+        for (int j = 0; j < sh->doc_log; ++j) point[j] = reef_fe{{0x1f83d9abfb41bd6bULL + j, 0x5be0cd19137e2179ULL, 0x3c6ef372fe94f82bULL, 0x0a54ff53a5f1d36fULL}};
+        std::vector<reef_fe> lz(row_len);
+        reef_fe ev;
+        CK(reef_mle_bound_rows(REEF_PALLAS, d_doc, n_doc, 1, REEF_DEVICE, true, point.data(), sh->doc_log, sh->doc_log / 2, lz.data(), REEF_HOST, &ev));
+        auto t0 = clk::now();
+        CK(reef_mle_bound_rows(REEF_PALLAS, d_doc, n_doc, 1, REEF_DEVICE, true, point.data(), sh->doc_log, sh->doc_log / 2, lz.data(), REEF_HOST, &ev));
+        mle_ms = ms_since(t0);
+        reef_device_free(d_row_gens);
+        reef_device_free(d_doc);
+    }
+    if (sh->table_log) {
+        const size_t len = (size_t)1 << sh->table_log;
+        reef_sc_ctx *sc = nullptr;
+        CK(reef_sc_create(&sc, REEF_PALLAS, len));
+        reef_fe *d_tab = (reef_fe *)reef_device_alloc(len * sizeof(reef_fe));
+        CK(reef_gen_scalars(REEF_PALLAS, 0x7AB1E, 2, 1u << 20, len, false, d_tab, REEF_DEVICE));   // packed lookup values, canonical
+        CK(reef_sc_set_table(sc, 0, d_tab, len, REEF_DEVICE));
+        reef_device_free(d_tab);
+        run_sumcheck_step(sc, sh->table_log, sh->lookups);            // warm-up
+        sc_step_ms = run_sumcheck_step(sc, sh->table_log, sh->lookups);
+        reef_sc_destroy(sc);
+    }
+
     const size_t pairs_step = sh->c2 + sh->w1 + sh->c1 + sh->w2;
     printf("{\"replay\": \"%s\", \"ipa\": \"%s\", \"note\": \"MSM work of reef --prove replayed through the C ABI; host-side proving work not included\", "
            "\"key_pallas\": %zu, \"key_vesta\": %zu, \"steps\": %d, \"setup_ms\": %.3f, \"fold_steps_ms\": %.3f, \"ms_per_step\": %.3f, "
            "\"pairs_per_step\": %zu, \"final_snark_ms\": %.3f, \"ipa_pallas_ms\": %.3f, \"ipa_pallas_rounds\": %d, \"ipa_vesta_ms\": %.3f, "
-           "\"ipa_vesta_rounds\": %d, \"consistency_ipa_ms\": %.3f, \"consistency_rounds\": %d, \"total_prove_msm_ms\": %.3f}\n",
+           "\"ipa_vesta_rounds\": %d, \"consistency_ipa_ms\": %.3f, \"consistency_rounds\": %d, \"total_prove_msm_ms\": %.3f, "
+           "\"commit_hyrax_ms\": %.3f, \"commit_hyrax_first_call_ms\": %.3f, \"sumcheck_table_log\": %d, \"sumcheck_ms_per_step\": %.3f, "
+           "\"doc_poly_bind_rows_ms\": %.3f, \"total_prove_gpu_ms\": %.3f}\n",
            sh->name, nofold ? "cross terms over the original key (no generator fold)" : "generator fold per round", cv[0].n, cv[1].n, sh->steps, setup_ms, steps_ms, steps_ms / sh->steps, pairs_step, final_ms, ipa1_ms, r1, ipa2_ms, r2,
-           cons_ms, r3, steps_ms + final_ms + cons_ms);
+           cons_ms, r3, steps_ms + final_ms + cons_ms, commit_ms, commit_first_ms, sh->table_log, sc_step_ms, mle_ms,
+           steps_ms + final_ms + cons_ms + sh->steps * sc_step_ms + mle_ms);
     for (Curve &c : cv) {
         reef_msm_ctx_destroy(c.key);
         for (auto &x : c.ipa) reef_msm_ctx_destroy(x);
