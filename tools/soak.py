@@ -8,8 +8,9 @@ import time
 import numpy as np
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from oracle import pasta_ref as R  # noqa: E402
-from reef_amd import msm  # noqa: E402
+from oracle import mle_oracle, pasta_ref as R, sumcheck_oracle as S  # noqa: E402
+from reef_amd import mle, msm  # noqa: E402
+from reef_amd.sumcheck import SumCheck  # noqa: E402
 
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
@@ -17,7 +18,7 @@ t_end = time.time() + budget
 done = 0
 while time.time() < t_end:
     cid = int(rng.integers(0, 2))
-    shape = rng.integers(0, 4)
+    shape = rng.integers(0, 6)
     if shape == 0:      # single MSM, any size
         n = int(2 ** rng.uniform(0, 21.2 if os.environ.get("SOAK_BIG") else 18.5))
         kind = int(rng.integers(0, 3))
@@ -47,6 +48,37 @@ while time.time() < t_end:
         bases = R.gen_bases_ap(cid, int(rng.integers(1, 1 << 30)), 3, n)
         sc = R.gen_scalars(cid, int(rng.integers(1, 1 << 30)), n, kind=int(rng.integers(0, 2)))
         assert msm.compress(cid, msm.mult_pippenger(cid, bases, sc)) == R.compress(cid, R.msm_pippenger(cid, bases, sc, threads=16)), ("pip", cid, n)
+    elif shape == 4:    # document polynomial: bound rows / evaluation
+        mod = S.Q if cid == 0 else mle_oracle.P
+        m = int(rng.integers(0, 13))
+        left = int(rng.integers(0, m + 1))
+        n = int(rng.integers(0, (1 << m) + 1))
+        point = [int.from_bytes(rng.bytes(32), "little") % mod for _ in range(m)]
+        if rng.random() < 0.5:
+            z = rng.integers(0, 256, size=n, dtype=np.uint8)
+            zi = [int(v) for v in z]
+        else:
+            zi = [int.from_bytes(rng.bytes(32), "little") % mod for _ in range(n)]
+            z = zi
+        assert mle.bound_rows("pallas" if cid == 0 else "vesta", z, point, left) == mle_oracle.bound_rows(zi, point, left, mod), ("mle", cid, m, left, n)
+    elif shape == 5:    # a whole sum-check (pallas scalar field)
+        ell = int(rng.integers(1, 11))
+        table = [int(rng.integers(0, 1 << 30)) for _ in range(int(rng.integers(1 << (ell - 1), (1 << ell) + 1)))]
+        nq = int(rng.integers(1, 6))
+        qs = [int(rng.integers(0, 1 << ell)) for _ in range(nq)]
+        rs = [int.from_bytes(rng.bytes(32), "little") % S.Q for _ in range(nq + 1)]
+        last_q = [int.from_bytes(rng.bytes(32), "little") % S.Q for _ in range(ell)]
+        t = table + [0] * ((1 << ell) - len(table))
+        e = S.gen_eq_table(rs, qs, last_q)
+        with SumCheck("pallas", ell) as sc:
+            sc.set_table(0, table)
+            sc.gen_eq_table(rs, qs, last_q)
+            for i in range(1, ell + 1):
+                assert sc.round_coeffs(i) == S.linear_mle_coeffs(t, e, ell, i), ("sc", ell, i)
+                r = int.from_bytes(rng.bytes(32), "little") % S.Q
+                sc.fold(i, r)
+                S.linear_mle_fold(t, e, ell, i, r)
+            assert sc.read(0, 1)[0] == t[0]
     else:               # rows (field elements and symbols)
         big = 2 if os.environ.get("SOAK_BIG") else 0
         rows, row_len = int(2 ** rng.uniform(0, 11 + big)), int(2 ** rng.uniform(0, 12 + big / 2))
