@@ -1,0 +1,186 @@
+// C++ host-side mirror of the nova-snark provider interface as eniac/Reef calls it, over the C ABI
+// of include/reef_msm.h (header only).  Reef is Rust; this image has no Rust toolchain, so the host
+// side above the ABI is written in C++ with the reference's names and argument meaning:
+//
+//   CommitmentGens<CURVE>::commit(v, blind)       CE::commit(&gens, &v, &blind)          src/backend/commitment.rs:349-351,360-361,422,430
+//   CommitmentGens<CURVE>::fold(w1, w2)           CommitmentGens::fold (ipa_pc)          reached from src/backend/framework.rs:695
+//   CommitmentGens<CURVE>::ipa_cross_terms(..)    the two cross-term commitments of an IPA round, without folding the generators
+//   HyraxPC<CURVE>::commit / commit_symbols       HyraxPC::commit(&poly)                 src/backend/commitment.rs:187
+//   HyraxPC<CURVE>::bind_rows                     first step of HyraxPC::prove_eval      src/backend/commitment.rs:371-391 (and :357)
+//   SumCheck                                      gen_eq_table / linear_mle_product      src/backend/r1cs_helper.rs:441-544, driven as in r1cs.rs:2318-2385
+//   compress()                                    Commitment::compress                   src/backend/commitment.rs:195,351,365
+//
+// Error behaviour: Reef treats every failure as a panic (framework.rs:683,702); here every failed
+// call throws reef_provider::Error carrying reef_last_error().
+#pragma once
+#include <array>
+#include <stdexcept>
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "reef_msm.h"
+
+namespace reef_provider {
+
+struct Error : std::runtime_error {
+    reef_status status;
+    Error(reef_status s, const char *what_failed) : std::runtime_error(std::string(what_failed) + ": " + reef_last_error()), status(s) {}
+};
+inline void check(reef_status s, const char *what) {
+    if (s != REEF_OK) throw Error(s, what);
+}
+
+using Compressed = std::array<uint8_t, 32>;
+
+template <int CURVE> inline Compressed compress(const reef_jacobian &p) {
+    Compressed c;
+    check(reef_normalize(CURVE, &p, 1, REEF_HOST, nullptr, c.data()), "reef_normalize");
+    return c;
+}
+
+// nova-snark CommitmentGens<G>: a vector of generators (+ blinding generator h) resident on the GPU,
+// pre-shifted once (commitment keys are fixed for the life of PublicParams, framework.rs:45,297-303).
+template <int CURVE> class CommitmentGens {
+  public:
+    CommitmentGens(const reef_affine *gens, size_t n, int gens_loc = REEF_HOST, const reef_affine *h = nullptr, bool preshift = true)
+        : n_(n), has_h_(h != nullptr) {
+        reef_msm_opts o = {};
+        o.bucket_groups = preshift ? 1 : 0;
+        o.device = -1;
+        check(reef_msm_ctx_create(&ctx_, CURVE, gens, n, gens_loc, &o), "reef_msm_ctx_create");
+        if (h) h_ = *h;
+    }
+    ~CommitmentGens() { reef_msm_ctx_destroy(ctx_); }
+    CommitmentGens(const CommitmentGens &) = delete;
+    CommitmentGens &operator=(const CommitmentGens &) = delete;
+
+    size_t len() const { return n_; }
+    reef_msm_ctx *handle() const { return ctx_; }
+    const reef_affine *h() const { return has_h_ ? &h_ : nullptr; }
+
+    // CE::commit: sum v_i G_i (+ blind * h).  Scalars in the pasta ABI form (Montgomery), host or device.
+    reef_jacobian commit(const reef_fe *v, size_t n, const reef_fe *blind = nullptr, int v_loc = REEF_HOST) const {
+        reef_jacobian out;
+        if (blind) {
+            if (!has_h_) throw std::logic_error("commit with a blind needs the blinding generator");
+            if (v_loc != REEF_HOST) throw std::logic_error("blind and h live where the scalars live: host");
+            check(reef_msm_rows(ctx_, v, 1, n, REEF_HOST, true, 0, blind, &h_, &out, REEF_HOST), "reef_msm_rows");
+        } else {
+            check(reef_msm(ctx_, v, n, v_loc, true, &out, REEF_HOST), "reef_msm");
+        }
+        return out;
+    }
+
+    // CommitmentGens::fold(w1, w2): G'_i = w1 * G_i + w2 * G_{i + n/2}; w canonical little-endian.
+    static std::vector<reef_affine> fold(const reef_affine *gens, size_t n, const reef_fe &w1, const reef_fe &w2) {
+        std::vector<reef_affine> out(n / 2);
+        check(reef_fold(CURVE, gens, n / 2, REEF_HOST, &w1, &w2, out.data()), "reef_fold");
+        return out;
+    }
+
+    // Cross terms (L, R) of IPA round k = w1s.size() over THESE generators (no fold): a = a_lo || a_hi.
+    std::pair<reef_jacobian, reef_jacobian> ipa_cross_terms(const reef_fe *a, size_t n_k, const std::vector<reef_fe> &w1s,
+                                                            const std::vector<reef_fe> &w2s, int a_loc = REEF_HOST) const {
+        if (w1s.size() != w2s.size()) throw std::logic_error("one (w1, w2) pair per round");
+        std::pair<reef_jacobian, reef_jacobian> lr;
+        check(reef_ipa_cross_terms(ctx_, a, n_k, a_loc, true, w1s.data(), w2s.data(), w1s.size(), &lr.first, &lr.second), "reef_ipa_cross_terms");
+        return lr;
+    }
+
+  private:
+    reef_msm_ctx *ctx_ = nullptr;
+    size_t n_;
+    reef_affine h_ = {};
+    bool has_h_;
+};
+
+// nova-snark (fork) HyraxPC as Reef builds it at commitment.rs:182-185: 2^right row generators and the
+// blinding generator; the polynomial's 2^l evaluations are viewed as a 2^left x 2^right matrix.
+template <int CURVE> class HyraxPC {
+  public:
+    explicit HyraxPC(const CommitmentGens<CURVE> &gens_v) : gens_(gens_v) {
+        if (!gens_v.h()) throw std::logic_error("HyraxPC needs a blinding generator");
+    }
+    static std::pair<size_t, size_t> compute_factored_lens(size_t num_vars) { return {num_vars / 2, num_vars - num_vars / 2}; }
+
+    // HyraxPC::commit(&poly): one commitment per matrix row, sum_j Z[i,j] G_j + blinds[i] h.
+    std::vector<reef_jacobian> commit(const reef_fe *poly, size_t num_vars, const reef_fe *blinds, uint32_t max_scalar_bits = 0) const {
+        const auto lr = compute_factored_lens(num_vars);
+        const size_t rows = (size_t)1 << lr.first, row_len = (size_t)1 << lr.second;
+        if (row_len > gens_.len()) throw std::logic_error("not enough row generators");
+        std::vector<reef_jacobian> out(rows);
+        check(reef_msm_rows(gens_.handle(), poly, rows, row_len, REEF_HOST, true, max_scalar_bits, blinds, gens_.h(), out.data(), REEF_HOST),
+              "reef_msm_rows");
+        return out;
+    }
+    // The same from the document symbols themselves (one byte each, < 2^symbol_bits; framework.rs:978-1011).
+    std::vector<reef_jacobian> commit_symbols(const uint8_t *symbols, size_t num_vars, uint32_t symbol_bits, const reef_fe *blinds,
+                                              int symbols_loc = REEF_HOST) const {
+        const auto lr = compute_factored_lens(num_vars);
+        const size_t rows = (size_t)1 << lr.first, row_len = (size_t)1 << lr.second;
+        if (row_len > gens_.len()) throw std::logic_error("not enough row generators");
+        std::vector<reef_jacobian> out(rows);
+        check(reef_msm_rows_symbols(gens_.handle(), symbols, rows, row_len, symbols_loc, symbol_bits, blinds, blinds ? gens_.h() : nullptr, true,
+                                    out.data(), REEF_HOST),
+              "reef_msm_rows_symbols");
+        return out;
+    }
+    // First step of prove_eval: LZ = L^T Z and eval = <LZ, R> for (L, R) = eq-evaluations of the two halves of `point`.
+    struct BoundRows {
+        std::vector<reef_fe> lz;
+        reef_fe eval;
+    };
+    BoundRows bind_rows(const void *z, size_t n, int elem_bytes, int z_loc, const reef_fe *point, size_t num_vars, bool is_mont = true) const {
+        const auto lr = compute_factored_lens(num_vars);
+        BoundRows b;
+        b.lz.resize((size_t)1 << lr.second);
+        check(reef_mle_bound_rows(CURVE, z, n, elem_bytes, z_loc, is_mont, point, num_vars, lr.first, b.lz.data(), REEF_HOST, &b.eval),
+              "reef_mle_bound_rows");
+        return b;
+    }
+
+  private:
+    const CommitmentGens<CURVE> &gens_;
+};
+
+// The nlookup sum-check of witness generation (r1cs.rs:2318-2385) over the scalar field of Pallas: resident
+// (table, eq) pair, one call per half of linear_mle_product; the Poseidon challenge stays with the caller.
+class SumCheck {
+  public:
+    SumCheck(size_t ell) : ell_(ell) { check(reef_sc_create(&sc_, REEF_PALLAS, (size_t)1 << ell), "reef_sc_create"); }
+    ~SumCheck() { reef_sc_destroy(sc_); }
+    SumCheck(const SumCheck &) = delete;
+    SumCheck &operator=(const SumCheck &) = delete;
+
+    void set_table(const reef_fe *values, size_t n, int loc = REEF_HOST) { check(reef_sc_set_table(sc_, 0, values, n, loc), "reef_sc_set_table"); }
+    void start_step() { check(reef_sc_reset_table(sc_), "reef_sc_reset_table"); }   // every folding step starts from the unfolded table
+    void gen_eq_table(const std::vector<reef_fe> &rs, const std::vector<uint32_t> &qs, const std::vector<reef_fe> &last_q) {
+        if (rs.size() != qs.size() + 1 || last_q.size() != ell_) throw std::logic_error("gen_eq_table: |rs| = |qs| + 1, |last_q| = ell");
+        check(reef_sc_gen_eq_table(sc_, rs.data(), qs.data(), qs.size(), last_q.data(), ell_), "reef_sc_gen_eq_table");
+    }
+    // round i in 1..ell: (xsq, x, con)
+    std::array<reef_fe, 3> round_coeffs(size_t i) {
+        std::array<reef_fe, 3> g;
+        check(reef_sc_round_coeffs(sc_, (size_t)1 << (ell_ - i), g.data()), "reef_sc_round_coeffs");
+        return g;
+    }
+    void fold(size_t i, const reef_fe &r) { check(reef_sc_fold(sc_, (size_t)1 << (ell_ - i), &r), "reef_sc_fold"); }
+    // fold of round i and the coefficients of round i + 1 in one pass (i < ell)
+    std::array<reef_fe, 3> fold_and_next_coeffs(size_t i, const reef_fe &r) {
+        std::array<reef_fe, 3> g;
+        check(reef_sc_fold_and_next_coeffs(sc_, (size_t)1 << (ell_ - i), &r, g.data()), "reef_sc_fold_and_next_coeffs");
+        return g;
+    }
+    reef_fe final_value() {   // prover_mle_partial_eval(table, sc_rs) after the last fold (r1cs.rs:2379-2385)
+        reef_fe v;
+        check(reef_sc_read(sc_, 0, 1, &v), "reef_sc_read");
+        return v;
+    }
+
+  private:
+    reef_sc_ctx *sc_ = nullptr;
+    size_t ell_;
+};
+
+}  // namespace reef_provider

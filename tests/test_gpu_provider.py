@@ -187,3 +187,59 @@ def test_hyrax_bind_rows_is_consistent_with_commit(gpu_lib, cref):
     zi = [v * pow(R, -1, Q) % Q for v in array_to_ints(z)]
     assert array_to_ints(ev)[0] == mle_oracle.evaluate(zi, point, Q) * R % Q
 
+
+def test_cpp_provider_mirror_matches_oracle(gpu_lib, cref):
+    """reef_amd/csrc/host/reef_provider.hpp (the C++ mirror of the provider interface Reef calls) through
+    its self-test program: every value it prints is recomputed here with the oracle from the same seeds."""
+    import json
+    import os
+    import subprocess
+    from oracle import mle_oracle, sumcheck_oracle as S
+    from reef_amd import _ffi
+    exe = os.path.join(os.path.dirname(_ffi.LIB_PATH), "provider_selftest")
+    assert os.path.exists(exe), "build() did not produce provider_selftest"
+    run = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert run.returncode == 0, run.stderr[-2000:]
+    got = json.loads(run.stdout.strip().splitlines()[-1])
+    # CE::commit
+    n = 1000
+    gens = cref.gen_bases_ap(0, 77, 13, n)
+    h = cref.gen_bases_ap(0, 0xB11D, 1, 1)[0].copy()
+    v = cref.gen_scalars(0, 4242, n, kind=1)
+    blind = cref.gen_scalars(0, 4243, 1)
+    assert got["commit"] == cref.compress(0, cref.msm_pippenger(0, gens, v, threads=4)).hex()
+    assert got["commit_blind"] == cref.compress(0, cref.row_msm(0, gens, v, 1, n, h=h, blinds=blind)).hex()
+    # HyraxPC::commit, both input forms
+    rows, cols = 16, 32
+    rg = cref.gen_bases_ap(0, 3, 7, cols)
+    z = cref.gen_scalars(0, 11, rows * cols, kind=2, small_bound=131)
+    bl = cref.gen_scalars(0, 12, rows)
+    want = cref.compress(0, cref.row_msm(0, rg, z, rows, cols, h=h, blinds=bl))
+    want_rows = [want[32 * i:32 * i + 32].hex() for i in range(rows)]
+    assert got["hyrax"] == want_rows and got["hyrax_symbols"] == want_rows
+    # prove_eval row binding
+    zc = [int(x) for x in cref.gen_scalars(0, 11, rows * cols, kind=2, small_bound=131, mont=False)[:, 0]]
+    point = [(0x1f83d9abfb41bd6b + j) | 0x5be0cd19137e2179 << 64 | 0x3c6ef372fe94f82b << 128 | 0x0a54ff53a5f1d36f << 192 for j in range(9)]
+    lz, ev = mle_oracle.bound_rows(zc, point, 4, S.Q)
+    assert got["bind_eval"] == ev.to_bytes(32, "little").hex() and got["bind_lz0"] == lz[0].to_bytes(32, "little").hex()
+    # IPA cross terms over Vesta, rounds 0 and 2 (generators folded by the oracle)
+    m = 256
+    ig = cref.gen_bases_ap(1, 21, 4, m)
+    a = cref.gen_scalars(1, 3, m)
+    assert got["ipa_l0"] == cref.compress(1, cref.msm_pippenger(1, ig[m // 2:].copy(), a[:m // 2].copy())).hex()
+    assert got["ipa_r0"] == cref.compress(1, cref.msm_pippenger(1, ig[:m // 2].copy(), a[m // 2:].copy())).hex()
+    g2 = cref.fold(1, cref.fold(1, ig, 5, 11), 7, 13)
+    q = m // 4
+    assert got["ipa_l2"] == cref.compress(1, cref.msm_pippenger(1, g2[q // 2:].copy(), a[:q // 2].copy())).hex()
+    assert got["ipa_r2"] == cref.compress(1, cref.msm_pippenger(1, g2[:q // 2].copy(), a[q // 2:q].copy())).hex()
+    # the reference's mle_linear_basic inputs through the C++ SumCheck
+    evals, qs, claims, last_q = [2, 3, 5, 7, 9, 13, 17, 19], [2, 1, 7], [3, 9, 27, 81], [5, 3, 2]
+    t, e = list(evals), S.gen_eq_table(claims, qs, last_q)
+    rs = [5, 1000003, 0x1234567890ABCDEF]
+    for i in range(1, 4):
+        want3 = [x.to_bytes(32, "little").hex() for x in S.linear_mle_coeffs(t, e, 3, i)]
+        assert got["sumcheck"][i - 1] == want3, i
+        S.linear_mle_fold(t, e, 3, i, rs[i - 1])
+    assert got["sumcheck_final"] == t[0].to_bytes(32, "little").hex()
+    assert got["error_throws"] is True
+
