@@ -6,6 +6,7 @@
 #include <string.h>
 
 #include "../ec.h"
+#include "../glv_host.h"
 
 using namespace reef;
 
@@ -76,6 +77,28 @@ void host_ec_op(int curve, int op, const void *p, const void *q, const void *k, 
 void host_accumulate(int curve, const void *pts, const uint8_t *neg, size_t n, void *out_jac, void *out_aff, void *out_comp) {
     if (curve == 0) accumulate<0>((const affine256 *)pts, neg, n, (jacobian256 *)out_jac, (affine256 *)out_aff, (fe256 *)out_comp);
     else accumulate<1>((const affine256 *)pts, neg, n, (jacobian256 *)out_jac, (affine256 *)out_aff, (fe256 *)out_comp);
+}
+// GLV split of a canonical scalar: out = k1[5], k2[5], neg1, neg2 (32-bit words); returns 1 on success
+int host_glv_split(int curve, const uint32_t *k8, uint32_t *out12) {
+    GlvSplit sp;
+    const bool ok = curve == 0 ? glv_split<0>(k8, &sp) : glv_split<1>(k8, &sp);
+    memcpy(out12, sp.k1, 20);
+    memcpy(out12 + 5, sp.k2, 20);
+    out12[10] = sp.neg1;
+    out12[11] = sp.neg2;
+    return ok ? 1 : 0;
+}
+// phi(P) = (beta * x, y) through the device/host-shared field code: out = affine ABI point
+void host_glv_phi(int curve, const void *p, void *out) {
+    if (curve == 0) {
+        affine a = affine_from_abi<0>(*(const affine256 *)p);
+        a.x = fe_mul<0>(a.x, fe_const<0>(GLV<0>::BETA, 1.0));
+        *(affine256 *)out = affine_to_abi<0>(a);
+    } else {
+        affine a = affine_from_abi<1>(*(const affine256 *)p);
+        a.x = fe_mul<1>(a.x, fe_const<1>(GLV<1>::BETA, 1.0));
+        *(affine256 *)out = affine_to_abi<1>(a);
+    }
 }
 // raw pack/unpack round trip (8 x u32 <-> 9 x 29-bit limbs)
 void host_pack_roundtrip(const void *in, void *out) {

@@ -407,6 +407,15 @@ def test_fold_golden_and_oracle(golden, gpu_lib, cref):
         w1, w2 = uniform_scalar(rng, C.order), uniform_scalar(rng, C.order)
         assert (msm.fold(cid, gens, 500, w1, w2) == cref.fold(cid, gens, w1, w2)).all()
         assert (msm.fold(cid, gens, 500, w1, w1) == cref.fold(cid, gens, w1, w1)).all()
+        # scalars at the edges of the endomorphism split (k = k1 + k2*lambda, 128-bit parts): zero parts, sign
+        # changes, r - 1, small values, powers of two; R_i = -L_i and R_i = L_i make sums collapse inside the table
+        gens[7] = gens[507]
+        gens[508] = np.frombuffer(C.affine_to_bytes(C.neg(C.affine_from_bytes(gens[8].tobytes()))), dtype=np.uint64)
+        gens[509] = 0
+        r = C.order
+        for a, b in ((0, 0), (0, 7), (7, 0), (1, 1), (r - 1, 1), (r - 1, r - 1), (1 << 127, 1 << 128), ((1 << 254) - 3, 5),
+                     (uniform_scalar(rng, r), 0), (3, uniform_scalar(rng, r))):
+            assert (msm.fold(cid, gens, 500, a, b) == cref.fold(cid, gens, a, b)).all(), (name, hex(a), hex(b))
 
 
 def test_normalize_matches_oracle(gpu_lib, cref):

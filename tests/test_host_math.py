@@ -5,6 +5,7 @@ the process).  The GPU parity tests check the same formulas as compiled for gfx9
 import ctypes
 import os
 import subprocess
+import sys
 
 import numpy as np
 import pytest
@@ -20,7 +21,7 @@ CID = {"pallas": 0, "vesta": 1}
 @pytest.fixture(scope="module")
 def host():
     src = os.path.join(CSRC, "tools", "host_check.cpp")
-    deps = [src] + [os.path.join(CSRC, f) for f in ("field.h", "ec.h", "field_consts.h")]
+    deps = [src] + [os.path.join(CSRC, f) for f in ("field.h", "ec.h", "field_consts.h", "glv_host.h", "glv_consts.h")]
     if not os.path.exists(SO) or os.path.getmtime(SO) < max(os.path.getmtime(d) for d in deps):
         os.makedirs(os.path.dirname(SO), exist_ok=True)
         subprocess.check_call(["g++", "-O2", "-std=c++17", "-DREEF_BOUNDS", "-shared", "-fPIC", src, "-o", SO])
@@ -30,6 +31,8 @@ def host():
     lib.host_ec_op.argtypes = [ctypes.c_int, ctypes.c_int, vp, vp, vp, vp, ctypes.c_size_t]
     lib.host_accumulate.argtypes = [ctypes.c_int, vp, vp, ctypes.c_size_t, vp, vp, vp]
     lib.host_pack_roundtrip.argtypes = [vp, vp]
+    lib.host_glv_split.argtypes = [ctypes.c_int, vp, vp]
+    lib.host_glv_phi.argtypes = [ctypes.c_int, vp, vp]
     return lib
 
 
@@ -138,3 +141,41 @@ def test_accumulate_chain_bounds(name, host, cref):
     host.host_accumulate(cid, two.ctypes.data, np.array([0, 0], dtype=np.uint8).ctypes.data, 2, jac.ctypes.data, aff.ctypes.data, comp.ctypes.data)
     p7 = C.affine_from_bytes(pts[7].tobytes())
     assert cref.compress(cid, jac) == C.compress(C.add(p7, p7))
+
+
+@pytest.mark.parametrize("name", ["pallas", "vesta"])
+def test_glv_split_and_endomorphism(name, host, cref):
+    """The generator fold halves its doubling chain with the curve endomorphism: phi(x, y) = (beta*x, y) must be
+    multiplication by lambda, and glv_split must return k = k1 + k2*lambda (mod r) with both parts below 2^128."""
+    import re
+    C = CURVES[name]
+    cid = CID[name]
+    r = C.order
+    hdr = open(os.path.join(CSRC, "glv_consts.h")).read()
+    blk = hdr[hdr.index("struct GLV<%d>" % cid):]
+    words = re.search(r"LAMBDA\[4\] = \{([^}]*)\}", blk).group(1)
+    lam = sum(int(w.strip().rstrip("ull"), 16) << (64 * i) for i, w in enumerate(words.split(",")))
+    assert (lam * lam + lam + 1) % r == 0
+    # phi(P) = lambda * P on a few points, through the shared field code
+    pts = cref.gen_bases_ap(cid, 12345, 678, 4)
+    for i in range(4):
+        out = np.zeros(8, dtype=np.uint64)
+        host.host_glv_phi(cid, pts[i].ctypes.data, out.ctypes.data)
+        P = C.affine_from_bytes(pts[i].tobytes())
+        assert C.affine_from_bytes(out.tobytes()) == C.mul(lam, P)
+    rng = SplitMix64(42)
+    ks = [0, 1, 2, r - 1, r - 2, lam, (lam * lam) % r, 1 << 128, (1 << 254) - 1] + [uniform_scalar(rng, r) for _ in range(300)]
+    for k in ks:
+        kw = np.array([(k >> (32 * i)) & 0xFFFFFFFF for i in range(8)], dtype=np.uint32)
+        out = np.zeros(12, dtype=np.uint32)
+        assert host.host_glv_split(cid, kw.ctypes.data, out.ctypes.data) == 1
+        k1 = sum(int(out[i]) << (32 * i) for i in range(5)) * (-1 if out[10] else 1)
+        k2 = sum(int(out[5 + i]) << (32 * i) for i in range(5)) * (-1 if out[11] else 1)
+        assert (k1 + k2 * lam - k) % r == 0, hex(k)
+        assert abs(k1) < 1 << 128 and abs(k2) < 1 << 128, hex(k)
+
+
+def test_glv_consts_generated_file_is_current():
+    gen = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "gen_glv_consts.py")], capture_output=True, text=True, check=True).stdout
+    assert gen == open(os.path.join(CSRC, "glv_consts.h")).read(), "run tools/gen_glv_consts.py > reef_amd/csrc/glv_consts.h"
+
