@@ -18,7 +18,7 @@ t_end = time.time() + budget
 done = 0
 while time.time() < t_end:
     cid = int(rng.integers(0, 2))
-    shape = rng.integers(0, 6)
+    shape = rng.integers(0, 7)
     if shape == 0:      # single MSM, any size
         n = int(2 ** rng.uniform(0, 21.2 if os.environ.get("SOAK_BIG") else 18.5))
         kind = int(rng.integers(0, 3))
@@ -48,6 +48,16 @@ while time.time() < t_end:
         bases = R.gen_bases_ap(cid, int(rng.integers(1, 1 << 30)), 3, n)
         sc = R.gen_scalars(cid, int(rng.integers(1, 1 << 30)), n, kind=int(rng.integers(0, 2)))
         assert msm.compress(cid, msm.mult_pippenger(cid, bases, sc)) == R.compress(cid, R.msm_pippenger(cid, bases, sc, threads=16)), ("pip", cid, n)
+    elif shape == 6:    # generator fold (endomorphism split of both scalars)
+        half = int(2 ** rng.uniform(0, 11))
+        gens = R.gen_bases_ap(cid, int(rng.integers(1, 1 << 30)), 7, 2 * half)
+        if half > 4:
+            gens[rng.integers(0, 2 * half, size=2)] = 0
+            gens[1] = gens[half + 1]
+        order = S.Q if cid == 0 else mle_oracle.P
+        pick = lambda: int(rng.choice([0, 1, 2, order - 1, 1 << 127, 1 << 128])) if rng.random() < 0.3 else int.from_bytes(rng.bytes(32), "little") % order  # noqa: E731
+        w1, w2 = pick(), pick()
+        assert (msm.fold(cid, gens, half, w1, w2) == R.fold(cid, gens, w1, w2)).all(), ("fold", cid, half, hex(w1), hex(w2))
     elif shape == 4:    # document polynomial: bound rows / evaluation
         mod = S.Q if cid == 0 else mle_oracle.P
         m = int(rng.integers(0, 13))
