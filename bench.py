@@ -9,8 +9,13 @@ own 2^20 points of one N*2^20-point MSM (weak scaling), the 96-byte partial sums
 with an RCCL all-gather and added on the device (RCCL has no elliptic-curve reduction).
 Rank 0 prints ONE JSON line.  `roofline` is measured live with HIP events on the stream the
 accumulation kernel is launched on; `cpu_baseline` times the oracle's C restatement of the CPU
-Pippenger on the host cores (rank 0, N = 1 only, bounded sample) -- it is the checker, never the
+Pippenger on ALL host cores (rank 0, N = 1 only, bounded sample) -- it is the checker, never the
 product path.
+
+What `value` includes: key AND scalars are resident in HBM when the timed region starts
+(`config.scalars` says so); the PCIe-inclusive rate of the same workload -- scalars in pinned host
+memory, result back in host memory, the same MSMs in flight -- is measured after the timed region and
+reported as `config.host_scalars_ms_per_step`; it is never `value`.
 """
 from __future__ import annotations
 
@@ -55,8 +60,9 @@ def parse():
     return p.parse_args()
 
 
-def expected_via_dlog(curve_name, canon, k0, d, offset):
-    """(sum_i s_i * (k0 + (offset+i)*d)) * G with O(n) big-int work (bases are an arithmetic progression)."""
+def dlog_of_msm(curve_name, canon, k0, d, offset):
+    """sum_i s_i * (k0 + (offset+i)*d) mod the group order: the discrete log of an MSM over bases in
+    arithmetic progression, with O(n) big-int work."""
     import numpy as np
     from oracle.pasta_oracle import CURVES
     C = CURVES[curve_name]
@@ -66,14 +72,20 @@ def expected_via_dlog(curve_name, canon, k0, d, offset):
     for j in range(4):
         col = canon[:, j].astype(object)
         acc += (int(col.sum()) * k0 + int((col * idx).sum()) * d) << (64 * j)
-    return C.compress(C.mul(acc % C.order, C.gen))
+    return acc % C.order
+
+
+def point_of_dlog(curve_name, k):
+    from oracle.pasta_oracle import CURVES
+    C = CURVES[curve_name]
+    return C.compress(C.mul(k % C.order, C.gen))
 
 
 def cpu_baseline(curve_id, seconds):
     """Oracle C Pippenger (halo2-style cpu_best_multiexp restatement) on all host cores."""
     from oracle import pasta_ref as R
     cores = os.cpu_count() or 1
-    threads = min(cores, 64)
+    threads = cores                              # every host core (the restatement deals the points out in chunks, one per thread)
     n = 1 << 14
     bases = R.gen_bases_ap(curve_id, 3, 5, n)
     sc = R.gen_scalars(curve_id, 0x5EEF, n)
@@ -94,8 +106,8 @@ def cpu_baseline(curve_id, seconds):
         spent += time.perf_counter() - t0
         reps += 1
     return {"value": n * reps / spent, "unit": "pairs/s", "cores": threads, "kind": "port",
-            "sample": f"{reps} x 2^{logn}-point Pallas MSM, uniform scalars, oracle/pasta_ref.c (cpu_best_multiexp restatement), "
-                      f"{threads} threads of {cores} host cores"}
+            "sample": f"{reps} x 2^{logn}-point Pallas MSM, uniform scalars, oracle/pasta_ref.c (cpu_best_multiexp restatement, NOT the "
+                      f"reference binary: Reef is Rust and cannot be built here), {threads} threads = all {cores} host cores"}
 
 
 def main():
@@ -154,13 +166,22 @@ def main():
     parts = [torch.zeros(96, dtype=torch.uint8, device=dev) for _ in range(nctx)]
     gathered = [torch.zeros(96 * a.gpus, dtype=torch.uint8, device=dev) for _ in range(nctx)]
     results = [torch.zeros(96, dtype=torch.uint8, device=dev) for _ in range(nctx)]
-    ext = None
-    if multi and a.backend == "nccl":
-        try:                       # run the collective on the MSM's own HIP stream (no host sync per step)
-            ext = [torch.cuda.ExternalStream(c.stream, device=dev) for c in ctxs]
-        except Exception as e:     # older torch: fall back to a host sync before the collective
-            print(f"[bench] ExternalStream unavailable ({e}); syncing before each all_gather", file=sys.stderr)
-            ext = None
+    # the exchange of N > 1 (reef_amd/distributed.py: all-gather of the 96-byte partial sums + on-device add); with RCCL
+    # the collective is ordered on the MSM's own HIP stream, so a step needs no host sync
+    from reef_amd.distributed import PartialSumExchange
+    exch = None
+    if multi:
+        exch = []
+        for c in ctxs:
+            stream_ctx = None
+            if a.backend == "nccl":
+                try:
+                    es = torch.cuda.ExternalStream(c.stream, device=dev)
+                    stream_ctx = (lambda es_: (lambda: torch.cuda.stream(es_)))(es)
+                except Exception as e:     # older torch: order by a host sync before the collective
+                    print(f"[bench] ExternalStream unavailable ({e}); syncing before each all_gather", file=sys.stderr)
+            exch.append(PartialSumExchange((lambda c_: (lambda g, cnt, out: c_.sum_points(g.data_ptr(), cnt, out.data_ptr())))(c),
+                                           backend=a.backend, before_exchange=c.sync, stream_ctx=stream_ctx))
 
     def step(i):
         j = i % nctx
@@ -169,34 +190,21 @@ def main():
             c.msm(scalars, n, out=results[j].data_ptr())
         else:
             c.msm(scalars, n, out=parts[j].data_ptr())
-            if ext is not None:
-                with torch.cuda.stream(ext[j]):     # collective ordered after the MSM on the same stream
-                    dist.all_gather_into_tensor(gathered[j], parts[j])
-            elif a.backend == "nccl":               # RCCL on torch's stream, ordered by a host sync
-                c.sync()
-                dist.all_gather_into_tensor(gathered[j], parts[j])
-                torch.cuda.current_stream().synchronize()
-            else:                                   # host-staged gather (gloo): 96 B per rank through host memory
-                c.sync()
-                host = parts[j].cpu()
-                outs = [torch.empty_like(host) for _ in range(a.gpus)]
-                dist.all_gather(outs, host)
-                gathered[j].copy_(torch.cat(outs))
-                torch.cuda.synchronize()
-            c.sum_points(gathered[j].data_ptr(), a.gpus, results[j].data_ptr())
+            exch[j].combine(parts[j], gathered[j], results[j])
 
     def sync_all():
         for c in ctxs:
             c.sync()
         torch.cuda.synchronize()
 
-    if multi and ext is not None:
+    if multi and a.backend == "nccl":
         try:                       # first collective on an external stream: fall back to host-ordered calls if torch refuses
             step(0)
             sync_all()
         except Exception as e:
             print(f"[bench] collective on the MSM stream failed ({e}); ordering by host sync instead", file=sys.stderr)
-            ext = None
+            for x in exch:
+                x.stream_ctx = None
     for i in range(a.warmup):
         step(i)
     sync_all()
@@ -222,39 +230,92 @@ def main():
     calls = sum(s["calls"] for s in stats)
     acc_ms = sum(s["accumulate_ms"] for s in stats) / max(calls, 1)
     tot_ms = sum(s["total_ms"] for s in stats) / max(calls, 1)
+    last = (a.steps - 1) % nctx
+    final_parts = parts[last].cpu().numpy().copy()
+    final_result = results[last].cpu().numpy().copy()
+
+    # ---- after the timed region (none of this is `value`) ------------------------------------------------
+    # (1) the accumulation kernel with ONE MSM in flight: with several MSMs sharing the chip a launch is stretched by
+    #     its neighbours, so the per-launch duration above understates the kernel
+    single = None
+    host_ms = None
+    if not multi:
+        reps = max(3, min(10, a.steps))
+        for _ in range(reps):
+            ctx0.msm(scalars, n, out=results[0].data_ptr())
+            ctx0.sync()
+        s1 = ctx0.timing_stats(reset=True)
+        single = {"kernel_ms": s1["accumulate_ms"] / max(s1["calls"], 1), "msm_ms": s1["total_ms"] / max(s1["calls"], 1)}
+        # (2) the same workload with the scalars in pinned HOST memory and the result returned to the host (what Reef's
+        #     prover hands over): PCIe-inclusive, the same number of MSMs in flight on their own streams
+        try:
+            pin = torch.empty((n, 4), dtype=torch.int64, pin_memory=True)
+            pin.copy_(torch.from_numpy(scalars.to_host((n, 4)).view(np.int64)))
+            hs = pin.numpy().view(np.uint64)
+            import threading
+            outs = [np.zeros(12, dtype=np.uint64) for _ in ctxs]
+            hsteps = max(nctx, min(a.steps, 12))
+
+            def host_worker(j):               # one caller thread per resident-key clone, as nova's rayon workers would be
+                for _ in range(hsteps // nctx):
+                    ctxs[j].msm(hs, n, out=outs[j])
+            for j in range(nctx):             # warm-up (staging buffers)
+                ctxs[j].msm(hs, n, out=outs[j])
+            th = [threading.Thread(target=host_worker, args=(j,)) for j in range(nctx)]
+            t1 = time.perf_counter()
+            [x.start() for x in th]
+            [x.join() for x in th]
+            host_ms = (time.perf_counter() - t1) / ((hsteps // nctx) * nctx) * 1e3
+            if not a.no_check and msm.compress(a.curve, outs[0]) != msm.compress(a.curve, final_result.view(np.uint64)):
+                raise RuntimeError("host-scalar MSM differs from the device-scalar MSM")
+        except Exception as e:                 # never let the side measurement take the bench line down
+            print(f"[bench] host-scalar timing skipped: {e}", file=sys.stderr)
 
     check = "skipped"
+    partials_differ = None
     if not a.no_check:
-        # size-independent parity check of the last result (outside the timed region)
+        # size-independent parity check of the last result (outside the timed region): bases are an arithmetic
+        # progression, so every MSM over them has a known discrete log
         canon = msm.gen_scalars(a.curve, seed, n, kind=kind, mont=False)
-        local = expected_via_dlog(a.curve, canon, k0, d, owner * n)
-        # points: each rank's partial is its own slice's MSM; windows: only the combined point is an MSM
-        checked = results if (by_windows or not multi) else parts
-        got_local = msm.compress(a.curve, checked[(a.steps - 1) % nctx].cpu().numpy().view(np.uint64))
-        ok = got_local == local
-        if multi:
+        my_dlog = dlog_of_msm(a.curve, canon, k0, d, owner * n)
+        if not multi:
+            ok = msm.compress(a.curve, final_result.view(np.uint64)) == point_of_dlog(a.curve, my_dlog)
+        else:
             cdev = dev if a.backend == "nccl" else "cpu"
-            flag = torch.tensor([1 if ok else 0], device=cdev)
+            got_total = msm.compress(a.curve, final_result.view(np.uint64))
+            got_part = msm.compress(a.curve, final_parts.view(np.uint64))
+            if by_windows:                    # every rank holds the same MSM; only the combined point is one
+                total_dlog = my_dlog
+                ok = True
+            else:                             # points: the rank's partial is its own slice's MSM, the total is the sum of the slices
+                ok = got_part == point_of_dlog(a.curve, my_dlog)
+                words = torch.tensor([(my_dlog >> (32 * j)) & 0xFFFFFFFF for j in range(8)], dtype=torch.int64, device=cdev)
+                allw = [torch.zeros_like(words) for _ in range(a.gpus)]
+                dist.all_gather(allw, words)
+                total_dlog = sum(sum(int(v) << (32 * j) for j, v in enumerate(w.tolist())) for w in allw)
+            ok = ok and got_total == point_of_dlog(a.curve, total_dlog)     # EVERY rank checks the combined point against the expected total
+            partials_differ = (got_part != got_total) if a.gpus > 1 else None
+            flag = torch.tensor([1 if ok else 0, 1 if (partials_differ or a.gpus == 1) else 0], device=cdev)
             dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-            ok = bool(flag.item())
-            # all ranks must hold the same combined point
-            comb = results[(a.steps - 1) % nctx].clone().to(cdev)
-            ref = comb.clone()
-            dist.broadcast(ref, 0)
-            ok = ok and bool((ref == comb).all().item())
+            ok = bool(flag[0].item())
+            if a.gpus > 1:
+                partials_differ = bool(flag[1].item())
         check = "dlog-ok" if ok else "MISMATCH"
 
     if rank == 0:
         # HBM traffic of the dominant kernel: PMC counters need their own rocprofv3 passes (never
         # combined with timing), so the value is read from the committed profile of this command
-        traffic = None
-        try:
-            prof = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
-            pc = prof["config"]
-            if (pc["curve"], pc["logn"], pc["window_bits"], pc["bucket_groups"]) == (a.curve, a.logn, plan["window_bits"], plan["bucket_groups"]):
-                traffic = prof["kernels"]["k_accum0<0>"]["hbm_bytes_per_launch"]
-        except (OSError, KeyError, ValueError):
-            pass
+        traffic, traffic_src = None, None
+        for prof_name in ("r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+            try:
+                prof = json.load(open(os.path.join(ROOT, "profiles", prof_name)))
+                pc = prof["config"]
+                if (pc["curve"], pc["logn"], pc["window_bits"], pc["bucket_groups"]) == (a.curve, a.logn, plan["window_bits"], plan["bucket_groups"]):
+                    traffic = prof["kernels"]["k_accum0<0>"]["hbm_bytes_per_launch"]
+                    traffic_src = f"profiles/{prof_name} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes)"
+                    break
+            except (OSError, KeyError, ValueError):
+                pass
         pairs = n * (1 if by_windows else a.gpus) * a.steps
         value = pairs / elapsed
         achieved = BYTES_PER_PAIR * n / (acc_ms * 1e-3) / 1e9 if acc_ms > 0 else None
@@ -264,17 +325,26 @@ def main():
             "steps": a.steps, "warmup": a.warmup, "ms_per_step": elapsed / a.steps * 1e3, "higher_is_better": True,
             "scaling": "strong" if by_windows else "weak", "vs_baseline": None, "dtype": "u32", "data": "synthetic",
             "config": {"workload": f"2^{a.logn}-point {a.curve.capitalize()} MSM per GPU, {a.scalars} 255-bit scalars, "
-                                   f"resident key (BASELINE.json configs[1])",
+                                   f"resident key, device-resident scalars (BASELINE.json configs[1])",
+                       "scalars": "device-resident (generated on the GPU before the timed region; no PCIe traffic inside it)",
+                       "host_scalars_ms_per_step": host_ms,
+                       "host_scalars_note": "same MSMs with the scalars in pinned host memory and the result returned to the host, one caller "
+                                            "thread per stream; PCIe-inclusive, measured after the timed region, never `value`",
                        "points_per_gpu": n, "total_points": n * (1 if by_windows else a.gpus), "window_bits": plan["window_bits"],
                        "windows": plan["windows"], "bucket_groups": plan["bucket_groups"], "tables": plan["tables"],
                        "streams": nctx, "sharding": ("windows (w = rank mod N)" if by_windows else "points") if a.gpus > 1 else "none",
                        "exchange": ("none" if a.gpus == 1 else "rccl all_gather of 96 B partials + on-device add" if a.backend == "nccl"
                                     else "HOST-STAGED gloo all_gather of 96 B partials (debug fallback, not RCCL) + on-device add"),
-                       "check": check, "msm_ms_stream": tot_ms},
+                       "check": check, "partials_differ_from_total": partials_differ, "msm_ms_stream": tot_ms},
             "roofline": {"bound": "hbm", "kernel": "k_accum0 (bucket accumulation)", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": traffic,
-                         "traffic_source": "profiles/r01_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes)" if traffic else None,
+                         "traffic_source": traffic_src,
                          "kernel_ms": acc_ms, "algorithmic_bytes_per_launch": BYTES_PER_PAIR * n,
+                         "note": f"kernel_ms = average launch duration with {nctx} MSMs in flight (launches stretch each other); single_stream = one MSM in flight",
+                         "single_stream": ({"kernel_ms": single["kernel_ms"], "msm_ms": single["msm_ms"],
+                                            "achieved": BYTES_PER_PAIR * n / (single["kernel_ms"] * 1e-3) / 1e9,
+                                            "frac": BYTES_PER_PAIR * n / (single["kernel_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS}
+                                           if single and single["kernel_ms"] > 0 else None),
                          # the kernel is bound by integer issue, not HBM: whole-job field products per second
                          # (10 per bucket addition, one addition per non-zero digit ~ windows-1 per pair) against the
                          # measured chip-wide rate of the Montgomery product (reef_bench_fmul)

@@ -55,9 +55,12 @@ typedef enum {
  * Stateless: nothing is retained; bases are uploaded per call.  `is_mont` = scalars are in
  * Montgomery form (what the Rust wrapper passes).  abort()s on error.
  * ------------------------------------------------------------------------------------------- */
-/* (A key that keeps coming back is recognised by a fingerprint of its uploaded bytes and, from its third
- * call on, served from a resident pre-shifted copy; nothing the caller can observe is retained.
- * REEF_MSM_KEY_CACHE=0 in the environment turns this off.) */
+/* (A key that keeps coming back is nominated by a non-cryptographic fingerprint of its uploaded bytes,
+ * CONFIRMED byte for byte against a retained device copy, and, from its third call on, served from a
+ * resident pre-shifted copy; a fingerprint collision therefore costs a cache miss, never a wrong result,
+ * and nothing the caller can observe is retained.  Caches are per calling thread; their device memory is
+ * charged to one process-wide budget (REEF_MSM_KEY_CACHE_MB, default 16384); on an allocation failure the
+ * thread's cache is emptied and the call is served uncached.  REEF_MSM_KEY_CACHE=0 turns the cache off.) */
 void mult_pippenger_pallas(reef_jacobian *out, const reef_affine *points, size_t npoints,
                            const reef_fe *scalars, bool is_mont);
 void mult_pippenger_vesta(reef_jacobian *out, const reef_affine *points, size_t npoints,
@@ -192,7 +195,9 @@ reef_status reef_sc_gen_eq_table(reef_sc_ctx *ctx, const reef_fe *rs, const uint
                                  const reef_fe *last_q, size_t ell);
 /* Round with pow = 2^(ell - i): out = { xsq, x, con } (host). */
 reef_status reef_sc_round_coeffs(reef_sc_ctx *ctx, size_t pow, reef_fe out[3]);
-/* X[b] = X[b]*(1 - r) + X[b + pow]*r for b < pow, both tables, in place (asynchronous). */
+/* X[b] <- X[b]*(1 - r) + X[b + pow]*r for b < pow, both tables (asynchronous).  Only entries [0, pow) are
+ * written: after a fold the tables hold `pow` live entries each, and reads or rounds that reach beyond them
+ * are rejected with REEF_ERR_ARG until the table is set / reset (T) or generated (EQ) again. */
 reef_status reef_sc_fold(reef_sc_ctx *ctx, size_t pow, const reef_fe *r);
 /* reef_sc_fold(pow, r) and reef_sc_round_coeffs(pow / 2) in ONE pass over the tables (pow >= 2):
  * the fold of round i feeds the sums of round i+1 from registers. */

@@ -6,6 +6,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <atomic>
 #include <memory>
 #include <mutex>
 
@@ -290,36 +291,67 @@ namespace {
 // third appearance on the call runs on a resident pre-shifted copy (the bases still cross PCIe, but
 // import, the plain-key pipeline and the host-side window combine are skipped).  Keys seen once -- the
 // folded generators of an IPA round -- never get a resident copy.  REEF_MSM_KEY_CACHE=0 turns it off.
+//
+// The fingerprint only NOMINATES an entry: a hit is confirmed by comparing the uploaded bytes with the
+// copy retained next to the resident key (one more pass over two buffers), so a fingerprint collision
+// costs a miss, never a wrong commitment.  Caches are per calling thread (no lock on the MSM path), their
+// device memory is charged to one process-wide budget (REEF_MSM_KEY_CACHE_MB, default 16384 = 16 GiB of the
+// 288 GB), and an allocation failure anywhere on this path empties the thread's cache and retries once on
+// the plain, uncached path before the symbol gives up.
 struct KeyCacheEntry {
     uint64_t h[2] = {0, 0};
     size_t n = 0;
     reef_msm_ctx *resident = nullptr;
+    void *raw = nullptr;               // device copy of the bytes the resident key was built from
+    size_t charged = 0;                // bytes charged to the process-wide budget
     uint64_t last_use = 0;
 };
+std::atomic<size_t> g_cache_bytes{0};
+std::atomic<bool> g_process_exiting{false};   // TLS destructors of the main thread run after HIP may be gone
+static size_t cache_budget() {
+    static const size_t b = [] {
+        const char *e = getenv("REEF_MSM_KEY_CACHE_MB");
+        return (size_t)(e ? strtoull(e, nullptr, 10) : 16384ull) << 20;
+    }();
+    return b;
+}
+static void entry_drop(KeyCacheEntry &e) {
+    reef_msm_ctx_destroy(e.resident);
+    if (e.raw) reef_device_free(e.raw);
+    g_cache_bytes -= e.charged;
+    e.resident = nullptr; e.raw = nullptr; e.charged = 0;
+}
 struct TlsCtx {
     reef_msm_ctx *ctx[2] = {nullptr, nullptr};
     void *stage = nullptr;
     size_t stage_cap = 0;
     std::vector<KeyCacheEntry> cache[2];
     uint64_t tick = 0;
+    void drop_cache() {
+        for (auto &v : cache) {
+            for (auto &e : v) entry_drop(e);
+            v.clear();
+        }
+    }
     ~TlsCtx() {
+        if (g_process_exiting.load()) return;          // process teardown: the driver reclaims everything
         for (auto *c : ctx) reef_msm_ctx_destroy(c);
-        for (auto &v : cache)
-            for (auto &e : v) reef_msm_ctx_destroy(e.resident);
+        drop_cache();
         if (stage) reef_device_free(stage);
     }
 };
 thread_local TlsCtx g_tls;
 constexpr size_t KEY_CACHE_MIN_POINTS = 1024, KEY_CACHE_ENTRIES = 6;
 
-static reef_status pippenger_try(int curve, reef_jacobian *out, const reef_affine *points, size_t npoints, const reef_fe *scalars, bool is_mont) {
-    static const bool cache_on = !(getenv("REEF_MSM_KEY_CACHE") && atoi(getenv("REEF_MSM_KEY_CACHE")) == 0);
+static reef_status pippenger_plain(int curve, reef_jacobian *out, const reef_affine *points, size_t npoints, int points_loc, const reef_fe *scalars,
+                                   bool is_mont) {
     reef_msm_ctx *&c = g_tls.ctx[curve];
-    if (!cache_on || npoints < KEY_CACHE_MIN_POINTS) {
-        if (!c) REEF_TRY(reef_msm_ctx_create(&c, curve, points, npoints, REEF_HOST, nullptr));
-        else REEF_TRY(vt(curve)->ctx_rekey(c->impl, points, npoints, REEF_HOST));
-        return reef_msm(c, scalars, npoints, REEF_HOST, is_mont, out, REEF_HOST);
-    }
+    if (!c) REEF_TRY(reef_msm_ctx_create(&c, curve, points, npoints, points_loc, nullptr));
+    else REEF_TRY(vt(curve)->ctx_rekey(c->impl, points, npoints, points_loc));
+    return reef_msm(c, scalars, npoints, REEF_HOST, is_mont, out, REEF_HOST);
+}
+
+static reef_status pippenger_cached(int curve, reef_jacobian *out, const reef_affine *points, size_t npoints, const reef_fe *scalars, bool is_mont) {
     const size_t bytes = npoints * sizeof(reef_affine);
     if (bytes > g_tls.stage_cap) {
         if (g_tls.stage) reef_device_free(g_tls.stage);
@@ -336,19 +368,37 @@ static reef_status pippenger_try(int curve, reef_jacobian *out, const reef_affin
         if (e.n == npoints && e.h[0] == h[0] && e.h[1] == h[1]) hit = &e;
     const uint64_t now = ++g_tls.tick;
     if (hit && hit->resident) {
-        hit->last_use = now;
-        return reef_msm(hit->resident, scalars, npoints, REEF_HOST, is_mont, out, REEF_HOST);
+        int same = 0;
+        REEF_TRY(vt(curve)->bytes_equal(g_tls.stage, hit->raw, bytes, &same));
+        if (same) {
+            hit->last_use = now;
+            return reef_msm(hit->resident, scalars, npoints, REEF_HOST, is_mont, out, REEF_HOST);
+        }
+        hit = nullptr;                                 // a fingerprint collision: this is another key, serve it uncached
+        return pippenger_plain(curve, out, (const reef_affine *)g_tls.stage, npoints, REEF_DEVICE, scalars, is_mont);
     }
     const reef_affine *staged = (const reef_affine *)g_tls.stage;
-    if (!c) REEF_TRY(reef_msm_ctx_create(&c, curve, staged, npoints, REEF_DEVICE, nullptr));
-    else REEF_TRY(vt(curve)->ctx_rekey(c->impl, staged, npoints, REEF_DEVICE));
-    REEF_TRY(reef_msm(c, scalars, npoints, REEF_HOST, is_mont, out, REEF_HOST));
-    if (hit) {                                         // second appearance: worth a resident pre-shifted copy
+    REEF_TRY(pippenger_plain(curve, out, staged, npoints, REEF_DEVICE, scalars, is_mont));
+    if (hit) {                                         // second appearance: worth a resident pre-shifted copy, if the budget allows
         hit->last_use = now;
+        uint32_t T = 1;
+        (void)reef_msm_plan_for(npoints, 0, 1, nullptr, nullptr, nullptr, &T);
+        const size_t cost = bytes * ((size_t)T + 1);   // T pre-shifted tables + the raw copy
+        if (g_cache_bytes.load() + cost > cache_budget()) return REEF_OK;
         reef_msm_opts o = {};
         o.bucket_groups = 1;
         o.device = -1;
-        if (reef_msm_ctx_create(&hit->resident, curve, staged, npoints, REEF_DEVICE, &o) != REEF_OK) hit->resident = nullptr;
+        void *raw = reef_device_alloc(bytes);
+        if (!raw) return REEF_OK;                       // no memory for a copy: keep serving this key uncached
+        if (reef_memcpy(raw, g_tls.stage, bytes, REEF_DEVICE, REEF_DEVICE) != REEF_OK ||
+            reef_msm_ctx_create(&hit->resident, curve, staged, npoints, REEF_DEVICE, &o) != REEF_OK) {
+            reef_device_free(raw);
+            hit->resident = nullptr;
+            return REEF_OK;
+        }
+        hit->raw = raw;
+        hit->charged = cost;
+        g_cache_bytes += cost;
         return REEF_OK;
     }
     if (cache.size() >= KEY_CACHE_ENTRIES) {           // forget the least recently used key
@@ -360,13 +410,27 @@ static reef_status pippenger_try(int curve, reef_jacobian *out, const reef_affin
             for (size_t i = 1; i < cache.size(); ++i)
                 if (cache[i].last_use < cache[lru].last_use) lru = i;
         }
-        reef_msm_ctx_destroy(cache[lru].resident);
+        entry_drop(cache[lru]);
         cache.erase(cache.begin() + lru);
     }
     KeyCacheEntry e;
     e.h[0] = h[0]; e.h[1] = h[1]; e.n = npoints; e.last_use = now;
     cache.push_back(e);
     return REEF_OK;
+}
+
+static reef_status pippenger_try(int curve, reef_jacobian *out, const reef_affine *points, size_t npoints, const reef_fe *scalars, bool is_mont) {
+    static const bool cache_on = !(getenv("REEF_MSM_KEY_CACHE") && atoi(getenv("REEF_MSM_KEY_CACHE")) == 0);
+    static std::once_flag exit_hook;
+    std::call_once(exit_hook, [] { atexit([] { g_process_exiting.store(true); }); });
+    reef_status st = (!cache_on || npoints < KEY_CACHE_MIN_POINTS) ? pippenger_plain(curve, out, points, npoints, REEF_HOST, scalars, is_mont)
+                                                                     : pippenger_cached(curve, out, points, npoints, scalars, is_mont);
+    if (st == REEF_ERR_OOM) {                           // give the cache's memory back and serve the call uncached
+        g_tls.drop_cache();
+        if (g_tls.stage) { reef_device_free(g_tls.stage); g_tls.stage = nullptr; g_tls.stage_cap = 0; }
+        st = pippenger_plain(curve, out, points, npoints, REEF_HOST, scalars, is_mont);
+    }
+    return st;
 }
 
 static void pippenger(int curve, reef_jacobian *out, const reef_affine *points, size_t npoints, const reef_fe *scalars, bool is_mont) {

@@ -41,6 +41,29 @@ def test_plan_for_host_logic():
         msm.plan_for(100, window_bits=25)
 
 
+def test_every_default_plan_is_runnable_up_to_the_key_limit():
+    """A plan the engine hands out must be one its pipeline accepts: the bucket keys of one MSM fit the scan
+    (G * 2^(c-1) <= 4 Mi keys) and its digits a 32-bit index, for every key length reef_msm_ctx_create
+    accepts (n < 2^27) and every bucket-group mode; what cannot run is rejected when the key is made."""
+    max_keys = 4 * 1024 * 1024
+    for logn in range(0, 27):
+        for n in {1 << logn, (1 << logn) + 1, (1 << (logn + 1)) - 1}:
+            if n >= 1 << 27:
+                continue
+            for groups in (0, 1, 2, 4, 7):
+                p = msm.plan_for(n, bucket_groups=groups)
+                c, w, g, t = p["window_bits"], p["windows"], p["bucket_groups"], p["tables"]
+                assert 2 <= c <= 20 and w == -(-256 // c) and t == -(-w // g)
+                assert (g << (c - 1)) <= max_keys, (n, groups, p)
+                assert n * w < 1 << 32, (n, groups, p)
+    assert msm.plan_for((1 << 27) - 1)["window_bits"] == 19      # the cost model asks for 20 there; 13 * 2^19 keys do not fit
+    with pytest.raises(msm.ReefError):
+        msm.plan_for(1 << 27)                                     # beyond the key limit
+    with pytest.raises(msm.ReefError):
+        msm.plan_for(1 << 24, window_bits=20)                     # an explicit plan that cannot run is refused, not clamped
+    assert msm.plan_for(1 << 24, window_bits=20, bucket_groups=1)["tables"] == 13
+
+
 def test_unknown_curve_rejected():
     with pytest.raises(ValueError):
         msm.curve_id("bls12")

@@ -1,7 +1,9 @@
-"""world_size-2 gloo tests (CPU) of the multi-GPU path: point sharding, the all-gather of 96-byte
-partial sums, the fixed combination order and the window split.  The group arithmetic is injected
-(the oracle stands in for the GPU calls, which need a device); what is under test is
-reef_amd/distributed.py -- the host logic the N > 1 bench path and a multi-GPU prover share."""
+"""world_size-2 gloo tests (CPU) of the multi-GPU path: point sharding, the window split with the engine's
+semantics (partial sums that add up), the all-gather of 96-byte partial sums and the fixed combination
+order.  The group arithmetic is injected (the oracle stands in for the GPU calls, which need a device);
+what is under test is reef_amd/distributed.py -- PartialSumExchange and the split functions that
+`bench.py --gpus N` drives with the C-ABI calls (tests/test_gpu_multirank.py runs that with two real
+ranks on a GPU)."""
 import os
 import socket
 
@@ -38,7 +40,9 @@ def _worker(rank, world, port, n, results):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         from oracle import pasta_ref as R
+        from oracle.pasta_oracle import CURVES
         cid = 0
+        order = CURVES["pallas"].order
         bases = R.gen_bases_ap(cid, 77, 3, n)
         scalars = R.gen_scalars(cid, 2024, n, kind=1)
         one = np.zeros((world, 4), dtype=np.uint64)
@@ -47,39 +51,33 @@ def _worker(rank, world, port, n, results):
         def local_msm(b, s):
             return R.msm_pippenger(cid, np.ascontiguousarray(b), np.ascontiguousarray(s), threads=1)
 
-        def add_points(jacs):
+        def sum_points(jacs):                                    # stand-in for reef_msm_ctx_sum_points
             aff = R.to_affine(cid, jacs)
             return R.msm_naive(cid, aff, one[: aff.shape[0]].copy(), mont=False)
 
-        combined = D.sharded_msm(local_msm, add_points, bases, scalars)
+        combined = D.point_sharded_msm(local_msm, sum_points, bases, scalars)
         comp = R.compress(cid, combined)
         expect = R.compress(cid, R.msm_pippenger(cid, bases, scalars, threads=1))
 
-        # window split: rank r owns windows w = r mod world (c = 16 -> 16 windows)
-        c, W = 16, 16
-        canon = np.zeros_like(scalars)
-        for i in range(n):
-            canon[i] = R.field_op("from_mont", 1, scalars[i].copy())   # Pallas scalars live in Fq
+        # window split as the engine does it (reef_msm_ctx_set_window_split): every rank recodes the whole scalar
+        # into signed c-bit digits and keeps the windows w = rank (mod world); its partial sum already carries the
+        # weights 2^(c*w), so partials combine by plain addition, exactly like point-sharded ones
+        c, W = 13, 20
+        canon = [R.limbs_to_int(R.field_op("from_mont", 1, scalars[i].copy())) for i in range(n)]   # Pallas scalars live in Fq
+        partial_holder = {}
 
-        def window_sums(ws):
-            out = []
-            for w in ws:
-                dig = np.zeros((n, 4), dtype=np.uint64)
-                word, sh = (w * c) // 64, (w * c) % 64
-                dig[:, 0] = (canon[:, word] >> np.uint64(sh)) & np.uint64((1 << c) - 1)
-                out.append(R.msm_pippenger(cid, bases, dig, mont=False, threads=1))
-            return out
+        def partial_msm(r, wd):
+            mine = D.owned_windows(W, wd, r)
+            sc = np.zeros((n, 4), dtype=np.uint64)
+            for i, k in enumerate(canon):
+                dig = D.signed_digits(k, c, W)
+                v = sum(dig[w] << (c * w) for w in mine) % order
+                sc[i] = [(v >> (64 * j)) & 0xFFFFFFFFFFFFFFFF for j in range(4)]
+            partial_holder["p"] = R.msm_pippenger(cid, bases, sc, mont=False, threads=1)
+            return partial_holder["p"]
 
-        def combine(sums):
-            aff = R.to_affine(cid, np.stack(sums))
-            sc = np.zeros((W, 4), dtype=np.uint64)
-            for w in range(W):
-                v = 1 << (c * w)
-                for j in range(4):
-                    sc[w, j] = (v >> (64 * j)) & 0xFFFFFFFFFFFFFFFF
-            return R.msm_naive(cid, aff, sc, mont=False)
-
-        wcomp = R.compress(cid, D.window_sharded_msm(window_sums, combine, W))
+        wcomp = R.compress(cid, D.window_split_msm(partial_msm, sum_points))
+        partial_is_not_total = R.compress(cid, partial_holder["p"]) != expect
 
         # row sharding (Hyrax commit): 5 rows over the same 64 generators, dealt out as 3 + 2
         rows, row_len = 5, 64
@@ -94,12 +92,12 @@ def _worker(rank, world, port, n, results):
         got_rows = D.sharded_rows(local_rows, rows, 12)
         want_rows = R.row_msm(cid, rb, rs, rows, row_len, h=h, blinds=bl)
         rows_ok = R.compress(cid, got_rows) == R.compress(cid, want_rows)
-        results[rank] = (comp == expect, wcomp == expect, comp.hex(), rows_ok)
+        results[rank] = (comp == expect, wcomp == expect, comp.hex(), rows_ok, partial_is_not_total, wcomp.hex())
     finally:
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("n", [1001])
+@pytest.mark.parametrize("n", [301])
 def test_sharded_msm_world2(n):
     world = 2
     mgr = mp.Manager()
@@ -107,6 +105,24 @@ def test_sharded_msm_world2(n):
     mp.spawn(_worker, args=(world, _free_port(), n, results), nprocs=world, join=True)
     assert len(results) == world
     assert all(results[r][0] for r in range(world)), "point-sharded result differs from the single-rank MSM"
-    assert all(results[r][1] for r in range(world)), "window-sharded result differs from the single-rank MSM"
-    assert results[0][2] == results[1][2], "ranks disagree on the combined point"
+    assert all(results[r][1] for r in range(world)), "window-split result differs from the single-rank MSM"
+    assert results[0][2] == results[1][2] and results[0][5] == results[1][5], "ranks disagree on the combined point"
     assert all(results[r][3] for r in range(world)), "row-sharded commitments differ from the single-rank batch"
+    assert all(results[r][4] for r in range(world)), "a window-split partial equals the whole MSM: nothing was split"
+
+
+def test_signed_digits_recompose_and_split():
+    """Host restatement of the engine's digit recoding: digits recompose the scalar, stay in the signed
+    range, and the windows dealt out to the ranks partition them."""
+    from oracle.pasta_oracle import CURVES, SplitMix64, uniform_scalar
+    q = CURVES["pallas"].order
+    rng = SplitMix64(17)
+    for c in (4, 13, 16, 17):
+        W = -(-256 // c)
+        for k in [0, 1, q - 1, (1 << (c - 1)), (1 << (c - 1)) + 1, (1 << c) - 1] + [uniform_scalar(rng, q) for _ in range(50)]:
+            d = D.signed_digits(k, c, W)
+            assert sum(v << (c * w) for w, v in enumerate(d)) == k
+            assert all(-(1 << (c - 1)) < v <= (1 << (c - 1)) for v in d)
+        for world in (1, 2, 3, 8):
+            owned = [D.owned_windows(W, world, r) for r in range(world)]
+            assert sorted(w for o in owned for w in o) == list(range(W))

@@ -85,9 +85,10 @@ def test_blind_combination_and_empty(gpu_lib):
     assert mle.bound_rows("pallas", [7], [], 0) == ([7], 7)          # zero variables: the constant
 
 
-@pytest.mark.parametrize("m,left,dtype,bound", [(21, 10, np.uint8, 131), (25, 12, np.uint8, 7)])
+@pytest.mark.parametrize("m,left,dtype,bound", [(21, 10, np.uint8, 131), (25, 12, np.uint8, 7), (27, 13, np.uint16, 55000)])
 def test_baseline_size_properties(m, left, dtype, bound, gpu_lib):
-    """BASELINE.json configs[2]/[3] sizes (1 MiB ASCII: 2^21; 16 MiB DNA: 2^25 symbols), device resident.
+    """BASELINE.json configs[2]/[3]/[4] sizes (1 MiB ASCII: 2^21; 16 MiB DNA: 2^25; 64 MiB UTF-8: 2^27 two-byte
+    symbols), device resident.
     Sampled columns of LZ against the oracle's definition, <LZ, R> against eval, a boolean left
     half reads a document row back, a boolean point reads a symbol back."""
     from reef_amd import mle, msm

@@ -1,0 +1,51 @@
+"""The N > 1 path of bench.py with TWO REAL RANKS: `python -m torch.distributed.run --nproc-per-node 2 bench.py --gpus 2`,
+exactly as the driver launches it, on the one GPU a test box has (the ranks share device 0; the 96-byte partial sums
+are exchanged through gloo, which bench.py labels as the host-staged fallback -- RCCL needs one device per rank).
+Both splits: by points (every rank owns its own 2^logn pairs, weak scaling) and by Pippenger window (one MSM, rank r
+accumulates the windows w = r mod 2 through reef_msm_ctx_set_window_split, strong scaling).  Every rank checks the
+COMBINED point against the discrete-log closed form of the whole MSM, and that its own partial is not already the total.
+"""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _run(sharding, logn, extra=()):
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--sharding", sharding,
+           "--logn", str(logn), "--steps", "6", "--warmup", "2", "--no-cpu-baseline", *extra]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [ln for ln in out.stdout.strip().splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]          # rank 0 prints ONE JSON line
+    return json.loads(lines[0])
+
+
+@pytest.mark.parametrize("sharding,logn", [("points", 16), ("windows", 16), ("windows", 18)])
+def test_bench_with_two_ranks(sharding, logn, gpu_lib):
+    line = _run(sharding, logn)
+    cfg = line["config"]
+    assert line["n_gpus"] == 2 and cfg["check"] == "dlog-ok"
+    assert cfg["partials_differ_from_total"] is True             # each rank really held a partial sum
+    assert "gloo" in cfg["exchange"]                             # labelled as the host-staged fallback, not as RCCL
+    if sharding == "points":
+        assert line["scaling"] == "weak" and cfg["total_points"] == 2 << logn and cfg["sharding"] == "points"
+    else:
+        assert line["scaling"] == "strong" and cfg["total_points"] == 1 << logn and cfg["sharding"].startswith("windows")
+    assert line["value"] > 0 and line["roofline"]["kernel_ms"] > 0

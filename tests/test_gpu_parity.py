@@ -226,7 +226,8 @@ def test_stateless_symbol_recognises_a_returning_key(name, gpu_lib, cref):
 
 
 @pytest.mark.parametrize("name,logn,kind,groups", [("pallas", 20, 0, 0), ("pallas", 20, 1, 0), ("vesta", 18, 0, 0),
-                                                   ("pallas", 18, 0, 1), ("vesta", 17, 1, 1)])
+                                                   ("pallas", 18, 0, 1), ("vesta", 17, 1, 1),
+                                                   ("pallas", 20, 0, 1), ("pallas", 20, 1, 1)])   # the last two: bench.py's plan
 def test_full_size_dlog_property(name, logn, kind, groups, gpu_lib):
     """BASELINE.json configs[1] size (2^20 Pallas): device-generated bases in arithmetic
     progression, so the result must equal (sum_i s_i*(k0 + i*d)) * G -- a size-independent check
@@ -240,6 +241,8 @@ def test_full_size_dlog_property(name, logn, kind, groups, gpu_lib):
     sc = sc_dev.to_host((n, 4))
     canon = msm.gen_scalars(name, 0x5EEF, n, kind=kind, mont=False)
     with msm.MsmContext(name, bases, n, bucket_groups=groups) as ctx:
+        if (logn, groups) == (20, 1):         # what bench.py measures: c = 17, one bucket group, 16 pre-shifted tables, two-level sort
+            assert ctx.plan() == {"window_bits": 17, "windows": 16, "bucket_groups": 1, "tables": 16}
         r_dev = ctx.msm(sc_dev, n)            # device-resident scalars
         r_host = ctx.msm(sc)                  # host scalars through the same key
         ctx.sync()
@@ -432,25 +435,34 @@ def test_normalize_matches_oracle(gpu_lib, cref):
         assert comp.tobytes() == cref.compress(cid, jac)
 
 
-@pytest.mark.parametrize("rows,row_len,bound", [(1024, 2048, 131), (512, 4096, 7)])
+@pytest.mark.parametrize("rows,row_len,bound", [(1024, 2048, 131), (512, 4096, 7), (4096, 8192, 7)])
 def test_rows_baseline_size_dlog_property(rows, row_len, bound, gpu_lib):
-    """HyraxPC::commit at BASELINE.json configs[2] size (1 MiB ASCII document = 1024 rows x 2048
-    symbols): bases in arithmetic progression, so row r must be (sum_j Z[r,j]*(k0 + j*d))*G."""
+    """HyraxPC::commit (src/backend/commitment.rs:173-187) at BASELINE.json configs[2] size (1 MiB ASCII document =
+    1024 rows x 2048 symbols) and configs[3] size (16 MiB DNA = 4096 rows x 8192 symbols < 7): bases in arithmetic
+    progression, so row r must be (sum_j Z[r,j]*(k0 + j*d))*G.  Both entry points: field-element scalars
+    (reef_msm_rows) and the document's own one-byte symbols (reef_msm_rows_symbols)."""
     from reef_amd import msm
     C = CURVES["pallas"]
     k0, d = 1234567, 89
     bases = msm.gen_bases("pallas", k0, d, row_len, device=True)
     sc = msm.gen_scalars("pallas", 0xD0C, rows * row_len, kind=2, small_bound=bound, device=True)
+    canon = msm.gen_scalars("pallas", 0xD0C, rows * row_len, kind=2, small_bound=bound, mont=False)
+    assert not canon[:, 1:].any()
+    sym = np.ascontiguousarray(canon[:, 0].astype(np.uint8))
+    del canon
     out = msm.DeviceBuffer(96 * rows)
+    out_sym = msm.DeviceBuffer(96 * rows)
     with msm.MsmContext("pallas", bases, row_len) as ctx:
         ctx.msm_rows(sc, rows, row_len, out=out)
+        dsym = msm.DeviceBuffer.from_host(sym)
+        ctx.msm_rows_symbols(dsym, rows, row_len, max(1, (bound - 1).bit_length()), out=out_sym)
         ctx.sync()
     comp = msm.compress("pallas", out.to_host((rows, 12)))
-    canon = msm.gen_scalars("pallas", 0xD0C, rows * row_len, kind=2, small_bound=bound, mont=False)[:, 0].astype(object)
-    canon = canon.reshape(rows, row_len)
-    w = k0 + np.arange(row_len, dtype=object) * d
+    assert msm.compress("pallas", out_sym.to_host((rows, 12))) == comp
+    mat = sym.reshape(rows, row_len).astype(np.int64)
+    w = k0 + np.arange(row_len, dtype=np.int64) * d             # < 2^21; symbols < 2^8; 2^13 terms: far below 2^63
     for r in list(range(0, rows, 97)) + [rows - 1]:
-        acc = int((canon[r] * w).sum()) % C.order
+        acc = int((mat[r] * w).sum()) % C.order
         assert comp[32 * r:32 * r + 32] == C.compress(C.mul(acc, C.gen)), r
 
 

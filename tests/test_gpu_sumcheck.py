@@ -71,37 +71,81 @@ def test_full_sumcheck_vs_oracle(curve, ell, n_t, gpu_lib):
         assert t[0] == verifier_mle_eval(table + [0] * ((1 << ell) - n_t), challenges, q)
 
 
-def test_baseline_size_identity(gpu_lib):
-    """cfg3 size (1 MiB document -> 2^21 entries): the sum-check identity claim = g(0) + g(1)
-    round after round, and small-symbol tables (document symbols < 131)."""
+@pytest.mark.parametrize("ell,fused", [(21, False), (26, True)])
+def test_baseline_size_identity(ell, fused, gpu_lib):
+    """cfg3 size (1 MiB document -> 2^21 entries) and cfg4 size (16 MiB DNA, --hybrid: 2^26 entries,
+    SURVEY.md 8): the sum-check identity claim = g(0) + g(1) round after round, the final claim
+    T~(r) * EQ~(r), and an independent O(n) check of the first round's constant term.  Tables are
+    generated on the device; document symbols < 131 / < 7 like the two configurations."""
     from reef_amd.sumcheck import SumCheck
     from reef_amd import msm
-    ell = 21
     n = 1 << ell
-    doc = msm.gen_scalars("pallas", 0xD0C, n, kind=2, small_bound=131, mont=False)       # canonical integers
-    eqv = msm.gen_scalars("pallas", 0xE9, n, kind=0, mont=False)
+    bound = 131 if ell == 21 else 7
+    d_doc = msm.gen_scalars("pallas", 0xD0C, n, kind=2, small_bound=bound, mont=False, device=True)   # canonical integers
+    d_eq = msm.gen_scalars("pallas", 0xE9, n, kind=0, mont=False, device=True)
+    half = n // 2
+    # con = sum_{b < n/2} T[b] * EQ[b]: symbols (< 2^8) times 32-bit pieces of EQ, summed in chunks that cannot overflow 64 bits
+    doc_lo = d_doc.to_host((half, 4))
+    assert not doc_lo[:, 1:].any() and int(doc_lo[:, 0].max()) < bound
+    sym = doc_lo[:, 0].copy()
+    del doc_lo
+    eq_lo = d_eq.to_host((half, 4))
+    chunk = 1 << 20
+    expect_con = 0
+    for j in range(4):
+        for piece, shift in ((eq_lo[:, j] & np.uint64(0xFFFFFFFF), 64 * j), (eq_lo[:, j] >> np.uint64(32), 64 * j + 32)):
+            prod = sym * piece                                   # < 2^8 * 2^32
+            expect_con += sum(int(prod[k:k + chunk].sum()) for k in range(0, half, chunk)) << shift
+    del eq_lo, sym
     with SumCheck("pallas", ell) as sc:
-        sc.set_table(0, doc)
-        sc.set_table(1, eqv)
+        sc.set_table_device(0, d_doc.ptr, n)
+        sc.set_table_device(1, d_eq.ptr, n)
         rng = SplitMix64(99)
         xsq, x, con = sc.round_coeffs(1)
-        # independent O(n) check of the first round's constant term with numpy object ints
-        d = [doc[:, j].astype(object) for j in range(4)]
-        e = [eqv[:, j].astype(object) for j in range(4)]
-        half = n // 2
-        dv = d[0][:half]                                        # symbols < 131 live in limb 0
-        ev = sum(e[j][:half] * (1 << (64 * j)) for j in range(4))
-        assert con == int((dv * ev).sum()) % Q
+        assert con == expect_con % Q
         claim = (2 * con + x + xsq) % Q
         for i in range(1, ell + 1):
-            if i > 1:
-                xsq, x, con = sc.round_coeffs(i)
-                assert claim == (2 * con + x + xsq) % Q, i
             r = uniform_scalar(rng, Q)
-            sc.fold(i, r)
-            claim = (xsq * r * r + x * r + con) % Q
+            claim_next = (xsq * r * r + x * r + con) % Q
+            if fused and i < ell:                                 # one pass per round (reef_sc_fold_and_next_coeffs)
+                xsq, x, con = sc.fold_and_next_coeffs(i, r)
+            else:
+                sc.fold(i, r)
+                if i < ell:
+                    xsq, x, con = sc.round_coeffs(i + 1)
+            claim = claim_next
+            if i < ell:
+                assert claim == (2 * con + x + xsq) % Q, i + 1
         t0, e0 = sc.read(0, 1)[0], sc.read(1, 1)[0]
         assert claim == t0 * e0 % Q                             # final claim = T~(r) * EQ~(r)
+        with pytest.raises(Exception):
+            sc.read(0, 2)                                       # only one live entry is left after the last fold
+        sc.reset_table()                                        # the next folding step starts from the unfolded table
+        assert sc.read(0, 4) == [int(v) for v in d_doc.to_host((4, 4))[:, 0]]
+
+
+def test_folded_tables_reject_reads_and_rounds_beyond_their_live_entries(gpu_lib):
+    """A fold writes entries [0, pow) only; what lies beyond is not the folded table and must not be served."""
+    from reef_amd.sumcheck import SumCheck
+    from reef_amd.msm import ReefError
+    ell = 6
+    t = list(range(1, 65))
+    with SumCheck("pallas", ell) as sc:
+        sc.set_table(0, t)
+        sc.set_table(1, t)
+        sc.fold(1, 3)                                            # 32 live entries per table
+        assert len(sc.read(0, 32)) == 32 and len(sc.read(1, 32)) == 32
+        for bad in (lambda: sc.read(0, 33), lambda: sc.read(1, 64), lambda: sc.round_coeffs(1), lambda: sc.fold(1, 5),
+                    lambda: sc.fold_and_next_coeffs(1, 5)):
+            with pytest.raises(ReefError):
+                bad()
+        sc.round_coeffs(2)                                       # the next round is fine
+        sc.reset_table()                                         # T is whole again, EQ is still folded
+        assert sc.read(0, 64) == t
+        with pytest.raises(ReefError):
+            sc.round_coeffs(1)
+        sc.set_table(1, t)
+        sc.round_coeffs(1)
 
 
 def test_fused_fold_and_next_coeffs(gpu_lib):
