@@ -1,0 +1,175 @@
+// Group operations spread over the FOUR waves of a 256-thread workgroup (device only).
+//
+// Why: the tail of an MSM (partial-sum merge, bucket reduction, generator fold) is a chain of dependent
+// group operations on a handful of waves.  A lone wave64 already saturates its SIMD's integer pipe
+// (one v_mad_u64_u32 per ~4.6 cycles, profiles/r01_lone_wave_issue.txt), so a general XYZZ addition
+// -- 14 field products one after the other -- takes 5.6 us whatever the number of active lanes.  The
+// products of one addition are not all dependent, though: they form 4 levels (doubling: 3), and a CU
+// has four SIMDs.  Here the four waves of a workgroup hold the SAME 64 operand pairs (replicated
+// registers, one pair per lane); at each level every wave computes ONE of the level's products for
+// all 64 lanes and the results are exchanged through LDS:
+//      addition   4 levels (mul, mul, mul, mul2_add)      instead of 12M + 2S in sequence   (3.45 us measured against 7.1 us)
+//      doubling   3 levels (sqr, mul, mul2_add)           instead of  6M + 3S               (2.65 us against 3.7 us)
+// Every wave leaves with the complete result, so the code around the operation (shuffles, selects,
+// loop control) simply runs replicated and wave-uniform decisions (`__any`) agree across the waves.
+//
+// LDS layout: one "slot" holds one field element per lane, limbs 0..7 as two 16-byte parts and
+// limb 8 as a dword, each part contiguous over the lanes: ds_read/write_b128 from 16 consecutive
+// lanes touch all 64 banks exactly once (MI355X_MICROARCH.md, LDS table), so no access conflicts.
+// Slots are never reused inside one operation and every level ends in a barrier, so one barrier per
+// level is enough (a wave cannot reach a slot's next write before all waves passed the three or four
+// barriers in between).
+//
+// Contract: blockDim.x == 256, every thread of the block calls the operation (no early exits), the
+// four waves pass identical operands.  Formulas and value bounds are those of ec.h
+// (xyzz_add / xyzz_dbl), where they are machine-checked on the host.
+#pragma once
+#include "ec.h"
+
+#if defined(__HIPCC__)
+namespace reef {
+
+static constexpr int COOP_SLOTS = 11;
+struct CoopLds {
+    uint4 q[COOP_SLOTS][2][64];
+    u32 t[COOP_SLOTS][64];
+    u32 flag[64];
+};
+
+__device__ __forceinline__ void coop_put(CoopLds &L, int slot, int lane, const fe &v) {
+    L.q[slot][0][lane] = make_uint4(v.l[0], v.l[1], v.l[2], v.l[3]);
+    L.q[slot][1][lane] = make_uint4(v.l[4], v.l[5], v.l[6], v.l[7]);
+    L.t[slot][lane] = v.l[8];
+}
+__device__ __forceinline__ fe coop_get(const CoopLds &L, int slot, int lane) {
+    const uint4 a = L.q[slot][0][lane], b = L.q[slot][1][lane];
+    fe r;
+    r.l[0] = a.x; r.l[1] = a.y; r.l[2] = a.z; r.l[3] = a.w;
+    r.l[4] = b.x; r.l[5] = b.y; r.l[6] = b.z; r.l[7] = b.w;
+    r.l[8] = L.t[slot][lane];
+    return r;
+}
+// One group operation by the four waves of the workgroup: mode COOP_ADD: a + b (both XYZZ, every special case of
+// xyzz_add in ec.h); mode COOP_DBL: 2*a (xyzz_dbl; b is ignored).  role = threadIdx.x >> 6, lane = threadIdx.x & 63.
+//
+// Addition and doubling run through the SAME inlined field products (three plain levels, then one level with a product
+// and a two-product form), only the cheap operand preparation differs by mode and role -- both wave-uniform scalars, so
+// it is scalar branches around register moves and LDS reads.  A kernel that funnels all its group operations through
+// one call of this function carries ~6 field products of code in total; with an inlined addition or doubling per use
+// the tail kernels were 40-580 KB and ran from a cold instruction cache most of the time.  The rare P + P case of an
+// addition (the formulas degenerate to ZZ3 = 0 with R = 0) simply takes a second pass in doubling mode.
+//
+//   level   addition (roles 0..3)                                   doubling (roles 0..3)
+//   1       u1 = X1*ZZ2 | u2 = X2*ZZ1 | s1 = Y1*ZZZ2 | s2 = Y2*ZZZ1  v = U^2 (U = 2Y) | xx = X^2 | - | -
+//   2       pp = P^2 (P = u2-u1) | zz12 | zzz12 | rr2 = R^2 (R = s2-s1)   w = U*v | s = X*v | mm = M^2 (M = 3xx) | ZZ3 = v*ZZ
+//   3       ppp = P*pp | ZZ3 = zz12*pp | q = u1*pp | -                (no third level)
+//   4       - | - | ZZZ3 = zzz12*ppp | X3 = rr2-ppp-2q, Y3 = R(q-X3)-s1*ppp     ZZZ3 = w*ZZZ | - | X3 = mm-2s, Y3 = M(s-X3)-w*Y | -
+enum { COOP_ADD = 0, COOP_DBL = 1 };
+template <int C> __device__ __forceinline__ xyzz xyzz_coop_op(int mode_, const xyzz &a, const xyzz &b, CoopLds &L, int role_, int lane) {
+    const int role = __builtin_amdgcn_readfirstlane(role_);
+    int mode = __builtin_amdgcn_readfirstlane(mode_);
+    const bool a_inf = xyzz_is_inf<C>(a);
+    const bool b_inf = mode == COOP_ADD && xyzz_is_inf<C>(b);
+    xyzz sum = xyzz_identity();                               // the addition's result while the rare second pass runs
+    bool same = false;
+    for (;;) {
+        const bool add = mode == COOP_ADD;
+        fe x = fe_zero(), y = fe_zero();
+        // ---- level 1
+        if (add) {
+            if (role == 0) { x = a.x; y = b.zz; }
+            else if (role == 1) { x = b.x; y = a.zz; }
+            else if (role == 2) { x = a.y; y = b.zzz; }
+            else { x = b.y; y = a.zzz; }
+        } else {
+            if (role == 0) { x = fe_dbl<C>(a.y); y = x; }     // U < 8
+            else { x = a.x; y = a.x; }
+        }
+        fe l1 = fe_zero();
+        if (add || role < 2) { l1 = fe_mul<C>(x, y); coop_put(L, role, lane, l1); }
+        __syncthreads();
+        // ---- level 2
+        fe keep = fe_zero();                                  // add: P (role 0), R (role 3); dbl: U (role 0), M (role 2)
+        if (add) {
+            if (role == 0) { keep = fe_sub<C, 2>(coop_get(L, 1, lane), l1); x = keep; y = keep; }        // P < 3.13
+            else if (role == 1) { x = a.zz; y = b.zz; }
+            else if (role == 2) { x = a.zzz; y = b.zzz; }
+            else { keep = fe_sub<C, 2>(l1, coop_get(L, 2, lane)); x = keep; y = keep; }                  // R < 3.07
+        } else {
+            if (role == 0) { keep = x; y = l1; }                                                          // U * v
+            else if (role == 1) { x = a.x; y = coop_get(L, 0, lane); }                                    // X * v
+            else if (role == 2) { const fe xx = coop_get(L, 1, lane); keep = fe_add<C>(fe_dbl<C>(xx), xx); x = keep; y = keep; }   // M < 4.5
+            else { x = coop_get(L, 0, lane); y = a.zz; }                                                  // v * ZZ
+        }
+        const fe l2 = fe_mul<C>(x, y);
+        if (add) {
+            if (role == 0) coop_put(L, 4, lane, l2);          // pp
+            if (role == 3) L.flag[lane] = fe_is_zero<C>(keep) ? 1u : 0u;
+        } else {
+            if (role == 0) coop_put(L, 5, lane, l2);          // w      (the slot of ppp: level 4 reads it as its second factor)
+            if (role == 1) coop_put(L, 6, lane, l2);          // s      (the slot of q)
+            if (role == 3) coop_put(L, 9, lane, l2);          // ZZ3
+        }
+        __syncthreads();
+        // ---- level 3 (addition only)
+        fe l3 = fe_zero();
+        if (add) {
+            const fe pp = coop_get(L, 4, lane);               // < 1.08
+            if (role == 0) x = keep;
+            else if (role == 1) x = l2;
+            else if (role == 2) x = coop_get(L, 0, lane);     // u1
+            if (role != 3) l3 = fe_mul<C>(x, pp);
+            if (role == 0) coop_put(L, 5, lane, l3);          // ppp
+            if (role == 2) coop_put(L, 6, lane, l3);          // q
+            if (role == 1) coop_put(L, 9, lane, l3);          // ZZ3
+            __syncthreads();
+        }
+        // ---- level 4: one role multiplies ZZZ3, another builds X3 and Y3; slot 5 = ppp | w, slot 6 = q | s
+        const int mul_role = add ? 2 : 0, xy_role = add ? 3 : 2;
+        if (role == mul_role) {
+            const fe f = add ? coop_get(L, 5, lane) : a.zzz;  // zzz12*ppp | w*ZZZ   (l2 = zzz12 | w)
+            coop_put(L, 10, lane, fe_mul<C>(l2, f));
+        } else if (role == xy_role) {
+            const fe p5 = coop_get(L, 5, lane);               // ppp < 1.03 | w < 1.1
+            const fe p6 = coop_get(L, 6, lane);               // q < 1.01   | s < 1.1
+            const fe t = add ? fe_add<C>(p5, fe_dbl<C>(p6)) : fe_dbl<C>(p6);        // ppp + 2q < 3.05 | 2s < 2.2
+            const fe x3 = fe_sub<C, 4>(l2, t);                // rr2 | mm : 1.16 + 4 -> < 5.2
+            const fe n1 = add ? fe_neg<C, 2>(coop_get(L, 2, lane)) : fe_neg<C, 4>(a.y);   // -s1 (s1 < 1.07) | -Y (Y < 4)
+            coop_put(L, 7, lane, x3);
+            coop_put(L, 8, lane, fe_mul2_add<C>(keep, fe_sub<C, 8>(p6, x3), n1, p5));      // R(q - X3) - s1*ppp | M(s - X3) - Y*w: < 1.4
+        }
+        __syncthreads();
+        xyzz r;
+        r.x = coop_get(L, 7, lane);
+        r.y = coop_get(L, 8, lane);
+        r.zz = coop_get(L, 9, lane);
+        r.zzz = coop_get(L, 10, lane);
+        if (!add) {
+            if (__builtin_amdgcn_readfirstlane(mode_) == COOP_DBL) return r;
+            sum = xyzz_select(same, r, sum);                  // second pass of an addition: 2a where a == b
+            break;
+        }
+        sum = r;
+        // P + P: then P = R = 0 and the formulas above give ZZ3 = 0; P + (-P) also gives ZZ3 = 0 but has R != 0.  Every wave
+        // holds the same lanes, so the test agrees across the workgroup.
+        same = L.flag[lane] != 0 && fe_is_zero<C>(r.zz) && !a_inf && !b_inf;
+        if (!__any(same)) break;
+        mode = COOP_DBL;
+        __syncthreads();                                      // slots 7..10 and the flag are read; the second pass may write again
+    }
+    if (__any(a_inf || b_inf)) {                              // an identity operand: the other one is the sum
+        sum = xyzz_select(a_inf, b, sum);
+        sum = xyzz_select(b_inf, a, sum);
+    }
+    return sum;
+}
+
+template <int C> __device__ __forceinline__ xyzz xyzz_add_coop(const xyzz &a, const xyzz &b, CoopLds &L, int role, int lane) {
+    return xyzz_coop_op<C>(COOP_ADD, a, b, L, role, lane);
+}
+template <int C> __device__ __forceinline__ xyzz xyzz_dbl_coop(const xyzz &p, CoopLds &L, int role, int lane) {
+    return xyzz_coop_op<C>(COOP_DBL, p, p, L, role, lane);
+}
+
+}  // namespace reef
+#endif

@@ -62,7 +62,7 @@ def test_group_law(name, gpu_lib, cref):
     from reef_amd import msm
     cid = CID[name]
     C = CURVES[name]
-    n = 64
+    n = 150                                 # three workgroups of the four-wave kernels, the last one ragged
     P = cref.gen_bases_ap(cid, 3, 5, n)
     Qp = cref.gen_bases_ap(cid, 1000, 9, n)
     # special cases: P == Q (doubling), P == -Q, identity operands
@@ -79,14 +79,15 @@ def test_group_law(name, gpu_lib, cref):
     out = np.zeros((n, 12), dtype=np.uint64)
     pts = [C.affine_from_bytes(P[i].tobytes()) for i in range(n)]
     qts = [C.affine_from_bytes(Qp[i].tobytes()) for i in range(n)]
-    for op in (0, 1, 2, 3):
+    for op in (0, 1, 2, 3, 4, 5, 6):       # 4-6: the same operations shared by the four waves of a workgroup (tail kernels)
         assert gpu_lib.reef_test_ec_op(cid, op, P.ctypes.data, Qp.ctypes.data, k.ctypes.data, out.ctypes.data, n) == 0
         comp = cref.compress(cid, out)
         gcomp = msm.compress(cid, out)
         assert comp == gcomp  # K4 normalise/compress on the GPU == oracle
         for i in range(n):
             exp = {0: lambda: C.add(pts[i], qts[i]), 1: lambda: C.add(pts[i], qts[i]), 2: lambda: C.add(pts[i], pts[i]),
-                   3: lambda: C.mul(ks[i], pts[i])}[op]()
+                   3: lambda: C.mul(ks[i], pts[i]), 4: lambda: C.add(pts[i], qts[i]), 5: lambda: C.add(pts[i], pts[i]),
+                   6: lambda: C.add(C.mul(4, C.add(pts[i], qts[i])), pts[i])}[op]()
             assert comp[32 * i:32 * i + 32] == C.compress(exp), (op, i)
 
 
