@@ -12,7 +12,7 @@ from ctypes import POINTER, c_bool, c_char_p, c_double, c_float, c_int, c_int32,
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
-LIB_PATH = os.path.join(_HERE, "_lib", "libreef_msm.so")
+LIB_PATH = os.environ.get("REEF_MSM_LIB") or os.path.join(_HERE, "_lib", "libreef_msm.so")   # REEF_MSM_LIB: another build of the same library (experiments)
 HEADER = os.path.join(os.path.dirname(_HERE), "include", "reef_msm.h")
 
 REEF_HOST, REEF_DEVICE = 0, 1

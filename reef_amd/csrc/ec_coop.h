@@ -35,7 +35,13 @@ struct CoopLds {
     u32 t[COOP_SLOTS][64];
     u32 flag[64];
 };
+#define COOP_SYNC() __syncthreads()
 
+// COMPILER NOTE.  hipcc of ROCm 7.2 at -O2 and above miscompiles two of these operations inlined back to back (a
+// doubling followed by a doubling: wrong ZZ, deterministic); -opt-bisect-limit on the stand-alone reproducer
+// tools/bisect/dd.hip stops at the AMDGPU load-store-vectorizer pass, and with -mllvm -amdgpu-load-store-vectorizer=0
+// every sequence is right (tools/dbg_ops.py checks all pairs and triples).  The library is therefore built with that
+// pass off (csrc/Makefile); volatile slot accesses alone cured the reproducer but not every sequence, and cost 30 %.
 __device__ __forceinline__ void coop_put(CoopLds &L, int slot, int lane, const fe &v) {
     L.q[slot][0][lane] = make_uint4(v.l[0], v.l[1], v.l[2], v.l[3]);
     L.q[slot][1][lane] = make_uint4(v.l[4], v.l[5], v.l[6], v.l[7]);
@@ -52,12 +58,12 @@ __device__ __forceinline__ fe coop_get(const CoopLds &L, int slot, int lane) {
 // One group operation by the four waves of the workgroup: mode COOP_ADD: a + b (both XYZZ, every special case of
 // xyzz_add in ec.h); mode COOP_DBL: 2*a (xyzz_dbl; b is ignored).  role = threadIdx.x >> 6, lane = threadIdx.x & 63.
 //
-// Addition and doubling run through the SAME inlined field products (three plain levels, then one level with a product
-// and a two-product form), only the cheap operand preparation differs by mode and role -- both wave-uniform scalars, so
-// it is scalar branches around register moves and LDS reads.  A kernel that funnels all its group operations through
-// one call of this function carries ~6 field products of code in total; with an inlined addition or doubling per use
-// the tail kernels were 40-580 KB and ran from a cold instruction cache most of the time.  The rare P + P case of an
-// addition (the formulas degenerate to ZZ3 = 0 with R = 0) simply takes a second pass in doubling mode.
+// Addition and doubling share ONE body (three plain product levels, then a level with a product and a two-product
+// form); the mode is a template parameter, the role a wave-uniform scalar, so operand preparation is scalar branches
+// around register moves and LDS reads and each level carries a single inlined field product.  Kernels keep to one
+// addition site (and one doubling site) per kernel: ~6 field products of code each, where an inlined operation per use
+// made the one-wave tail kernels 40-580 KB.  The rare P + P case of an addition (the formulas degenerate to ZZ3 = 0 with
+// R = 0) is one more shared doubling.
 //
 //   level   addition (roles 0..3)                                   doubling (roles 0..3)
 //   1       u1 = X1*ZZ2 | u2 = X2*ZZ1 | s1 = Y1*ZZZ2 | s2 = Y2*ZZZ1  v = U^2 (U = 2Y) | xx = X^2 | - | -
@@ -65,110 +71,107 @@ __device__ __forceinline__ fe coop_get(const CoopLds &L, int slot, int lane) {
 //   3       ppp = P*pp | ZZ3 = zz12*pp | q = u1*pp | -                (no third level)
 //   4       - | - | ZZZ3 = zzz12*ppp | X3 = rr2-ppp-2q, Y3 = R(q-X3)-s1*ppp     ZZZ3 = w*ZZZ | - | X3 = mm-2s, Y3 = M(s-X3)-w*Y | -
 enum { COOP_ADD = 0, COOP_DBL = 1 };
-template <int C> __device__ __forceinline__ xyzz xyzz_coop_op(int mode_, const xyzz &a, const xyzz &b, CoopLds &L, int role_, int lane) {
+template <int C, int MODE> __device__ __forceinline__ xyzz xyzz_coop_op(const xyzz &a, const xyzz &b, CoopLds &L, int role_, int lane) {
+    constexpr bool add = MODE == COOP_ADD;
     const int role = __builtin_amdgcn_readfirstlane(role_);
-    int mode = __builtin_amdgcn_readfirstlane(mode_);
-    const bool a_inf = xyzz_is_inf<C>(a);
-    const bool b_inf = mode == COOP_ADD && xyzz_is_inf<C>(b);
-    xyzz sum = xyzz_identity();                               // the addition's result while the rare second pass runs
-    bool same = false;
-    for (;;) {
-        const bool add = mode == COOP_ADD;
-        fe x = fe_zero(), y = fe_zero();
-        // ---- level 1
-        if (add) {
-            if (role == 0) { x = a.x; y = b.zz; }
-            else if (role == 1) { x = b.x; y = a.zz; }
-            else if (role == 2) { x = a.y; y = b.zzz; }
-            else { x = b.y; y = a.zzz; }
+    fe x, y;
+    // ---- level 1
+    if constexpr (add) {
+        if (role == 0) { x = a.x; y = b.zz; }
+        else if (role == 1) { x = b.x; y = a.zz; }
+        else if (role == 2) { x = a.y; y = b.zzz; }
+        else { x = b.y; y = a.zzz; }
+    } else {
+        if (role == 0) { x = fe_dbl<C>(a.y); y = x; }         // U < 8
+        else { x = a.x; y = a.x; }
+    }
+    fe l1 = x;
+    if (add || role < 2) { l1 = fe_mul<C>(x, y); coop_put(L, role, lane, l1); }
+    COOP_SYNC();
+    // ---- level 2
+    fe keep = x;                                              // add: P (role 0), R (role 3); dbl: U (role 0), M (role 2)
+    fe n1 = x;                                                // add, role 3: -s1, made while level 3 runs elsewhere
+    if constexpr (add) {
+        if (role == 0) { keep = fe_sub<C, 2>(coop_get(L, 1, lane), l1); x = keep; y = keep; }            // P < 3.13
+        else if (role == 1) { x = a.zz; y = b.zz; }
+        else if (role == 2) { x = a.zzz; y = b.zzz; }
+        else { n1 = coop_get(L, 2, lane); keep = fe_sub<C, 2>(l1, n1); x = keep; y = keep; }             // R < 3.07
+    } else {
+        if (role == 0) { y = l1; }                                                                        // U * v  (x, keep = U)
+        else if (role == 1) { x = a.x; y = coop_get(L, 0, lane); }                                        // X * v
+        else if (role == 2) { const fe xx = coop_get(L, 1, lane); keep = fe_add<C>(fe_dbl<C>(xx), xx); x = keep; y = keep; }   // M < 4.5
+        else { x = coop_get(L, 0, lane); y = a.zz; }                                                      // v * ZZ
+    }
+    const fe l2 = fe_mul<C>(x, y);
+    if constexpr (add) {
+        if (role == 0) coop_put(L, 4, lane, l2);              // pp
+        if (role == 3) L.flag[lane] = fe_is_zero<C>(keep) ? 1u : 0u;
+    } else {
+        if (role == 0) coop_put(L, 5, lane, l2);              // w      (the slot of ppp: level 4 reads it as its second factor)
+        if (role == 1) coop_put(L, 6, lane, l2);              // s      (the slot of q)
+        if (role == 3) coop_put(L, 9, lane, l2);              // ZZ3
+    }
+    COOP_SYNC();
+    // ---- level 3 (addition only)
+    if constexpr (add) {
+        if (role == 3) {
+            n1 = fe_neg<C, 2>(n1);                            // -s1, s1 < 1.07
         } else {
-            if (role == 0) { x = fe_dbl<C>(a.y); y = x; }     // U < 8
-            else { x = a.x; y = a.x; }
-        }
-        fe l1 = fe_zero();
-        if (add || role < 2) { l1 = fe_mul<C>(x, y); coop_put(L, role, lane, l1); }
-        __syncthreads();
-        // ---- level 2
-        fe keep = fe_zero();                                  // add: P (role 0), R (role 3); dbl: U (role 0), M (role 2)
-        if (add) {
-            if (role == 0) { keep = fe_sub<C, 2>(coop_get(L, 1, lane), l1); x = keep; y = keep; }        // P < 3.13
-            else if (role == 1) { x = a.zz; y = b.zz; }
-            else if (role == 2) { x = a.zzz; y = b.zzz; }
-            else { keep = fe_sub<C, 2>(l1, coop_get(L, 2, lane)); x = keep; y = keep; }                  // R < 3.07
-        } else {
-            if (role == 0) { keep = x; y = l1; }                                                          // U * v
-            else if (role == 1) { x = a.x; y = coop_get(L, 0, lane); }                                    // X * v
-            else if (role == 2) { const fe xx = coop_get(L, 1, lane); keep = fe_add<C>(fe_dbl<C>(xx), xx); x = keep; y = keep; }   // M < 4.5
-            else { x = coop_get(L, 0, lane); y = a.zz; }                                                  // v * ZZ
-        }
-        const fe l2 = fe_mul<C>(x, y);
-        if (add) {
-            if (role == 0) coop_put(L, 4, lane, l2);          // pp
-            if (role == 3) L.flag[lane] = fe_is_zero<C>(keep) ? 1u : 0u;
-        } else {
-            if (role == 0) coop_put(L, 5, lane, l2);          // w      (the slot of ppp: level 4 reads it as its second factor)
-            if (role == 1) coop_put(L, 6, lane, l2);          // s      (the slot of q)
-            if (role == 3) coop_put(L, 9, lane, l2);          // ZZ3
-        }
-        __syncthreads();
-        // ---- level 3 (addition only)
-        fe l3 = fe_zero();
-        if (add) {
             const fe pp = coop_get(L, 4, lane);               // < 1.08
             if (role == 0) x = keep;
             else if (role == 1) x = l2;
-            else if (role == 2) x = coop_get(L, 0, lane);     // u1
-            if (role != 3) l3 = fe_mul<C>(x, pp);
-            if (role == 0) coop_put(L, 5, lane, l3);          // ppp
-            if (role == 2) coop_put(L, 6, lane, l3);          // q
-            if (role == 1) coop_put(L, 9, lane, l3);          // ZZ3
-            __syncthreads();
+            else x = coop_get(L, 0, lane);                    // u1
+            const fe l3 = fe_mul<C>(x, pp);
+            coop_put(L, role == 0 ? 5 : role == 2 ? 6 : 9, lane, l3);   // ppp | q | ZZ3
         }
-        // ---- level 4: one role multiplies ZZZ3, another builds X3 and Y3; slot 5 = ppp | w, slot 6 = q | s
-        const int mul_role = add ? 2 : 0, xy_role = add ? 3 : 2;
-        if (role == mul_role) {
-            const fe f = add ? coop_get(L, 5, lane) : a.zzz;  // zzz12*ppp | w*ZZZ   (l2 = zzz12 | w)
-            coop_put(L, 10, lane, fe_mul<C>(l2, f));
-        } else if (role == xy_role) {
-            const fe p5 = coop_get(L, 5, lane);               // ppp < 1.03 | w < 1.1
-            const fe p6 = coop_get(L, 6, lane);               // q < 1.01   | s < 1.1
-            const fe t = add ? fe_add<C>(p5, fe_dbl<C>(p6)) : fe_dbl<C>(p6);        // ppp + 2q < 3.05 | 2s < 2.2
-            const fe x3 = fe_sub<C, 4>(l2, t);                // rr2 | mm : 1.16 + 4 -> < 5.2
-            const fe n1 = add ? fe_neg<C, 2>(coop_get(L, 2, lane)) : fe_neg<C, 4>(a.y);   // -s1 (s1 < 1.07) | -Y (Y < 4)
-            coop_put(L, 7, lane, x3);
-            coop_put(L, 8, lane, fe_mul2_add<C>(keep, fe_sub<C, 8>(p6, x3), n1, p5));      // R(q - X3) - s1*ppp | M(s - X3) - Y*w: < 1.4
-        }
-        __syncthreads();
-        xyzz r;
-        r.x = coop_get(L, 7, lane);
-        r.y = coop_get(L, 8, lane);
-        r.zz = coop_get(L, 9, lane);
-        r.zzz = coop_get(L, 10, lane);
-        if (!add) {
-            if (__builtin_amdgcn_readfirstlane(mode_) == COOP_DBL) return r;
-            sum = xyzz_select(same, r, sum);                  // second pass of an addition: 2a where a == b
-            break;
-        }
-        sum = r;
+        COOP_SYNC();
+    }
+    // ---- level 4: one role multiplies ZZZ3, another builds X3 and Y3; slot 5 = ppp | w, slot 6 = q | s
+    constexpr int mul_role = add ? 2 : 0, xy_role = add ? 3 : 2;
+    if (role == mul_role) {
+        fe f;
+        if constexpr (add) f = coop_get(L, 5, lane); else f = a.zzz;   // zzz12*ppp | w*ZZZ   (l2 = zzz12 | w)
+        coop_put(L, 10, lane, fe_mul<C>(l2, f));
+    } else if (role == xy_role) {
+        const fe p5 = coop_get(L, 5, lane);                   // ppp < 1.03 | w < 1.1
+        const fe p6 = coop_get(L, 6, lane);                   // q < 1.01   | s < 1.1
+        fe t;                                                 // ppp + 2q < 3.05 | 2s < 2.2, left un-normalised (limbs < 3 * 2^29 < 2^31 - 4)
+#pragma unroll
+        for (int i = 0; i < 9; ++i) t.l[i] = (add ? p5.l[i] : 0u) + 2u * p6.l[i];
+        const fe x3 = fe_sub<C, 4>(l2, t);                    // rr2 | mm : 1.16 + 4 -> < 5.2
+        if constexpr (!add) n1 = fe_neg<C, 4>(a.y);           // -Y (Y < 4)
+        coop_put(L, 7, lane, x3);
+        coop_put(L, 8, lane, fe_mul2_add<C>(keep, fe_sub<C, 8>(p6, x3), n1, p5));      // R(q - X3) - s1*ppp | M(s - X3) - Y*w: < 1.4
+    }
+    COOP_SYNC();
+    xyzz r;
+    r.x = coop_get(L, 7, lane);
+    r.y = coop_get(L, 8, lane);
+    r.zz = coop_get(L, 9, lane);
+    r.zzz = coop_get(L, 10, lane);
+    if constexpr (add) {
+        const bool a_inf = xyzz_is_inf<C>(a), b_inf = xyzz_is_inf<C>(b);
         // P + P: then P = R = 0 and the formulas above give ZZ3 = 0; P + (-P) also gives ZZ3 = 0 but has R != 0.  Every wave
-        // holds the same lanes, so the test agrees across the workgroup.
-        same = L.flag[lane] != 0 && fe_is_zero<C>(r.zz) && !a_inf && !b_inf;
-        if (!__any(same)) break;
-        mode = COOP_DBL;
-        __syncthreads();                                      // slots 7..10 and the flag are read; the second pass may write again
+        // holds the same lanes, so the test agrees across the workgroup and the rare doubling is one more shared operation.
+        const bool same = L.flag[lane] != 0 && fe_is_zero<C>(r.zz) && !a_inf && !b_inf;
+        if (__any(same)) {
+            COOP_SYNC();                                  // slots 7..10 and the flag are read everywhere
+            const xyzz d = xyzz_coop_op<C, COOP_DBL>(a, a, L, role_, lane);
+            r = xyzz_select(same, d, r);
+        }
+        if (__any(a_inf || b_inf)) {                          // an identity operand: the other one is the sum
+            r = xyzz_select(a_inf, b, r);
+            r = xyzz_select(b_inf, a, r);
+        }
     }
-    if (__any(a_inf || b_inf)) {                              // an identity operand: the other one is the sum
-        sum = xyzz_select(a_inf, b, sum);
-        sum = xyzz_select(b_inf, a, sum);
-    }
-    return sum;
+    return r;
 }
 
 template <int C> __device__ __forceinline__ xyzz xyzz_add_coop(const xyzz &a, const xyzz &b, CoopLds &L, int role, int lane) {
-    return xyzz_coop_op<C>(COOP_ADD, a, b, L, role, lane);
+    return xyzz_coop_op<C, COOP_ADD>(a, b, L, role, lane);
 }
 template <int C> __device__ __forceinline__ xyzz xyzz_dbl_coop(const xyzz &p, CoopLds &L, int role, int lane) {
-    return xyzz_coop_op<C>(COOP_DBL, p, p, L, role, lane);
+    return xyzz_coop_op<C, COOP_DBL>(p, p, L, role, lane);
 }
 
 }  // namespace reef
