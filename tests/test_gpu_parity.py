@@ -231,6 +231,58 @@ def test_stateless_symbol_recognises_a_returning_key(name, gpu_lib, cref):
             assert msm.compress(cid, msm.mult_pippenger(cid, kb, sck)) == w, rnd
 
 
+@pytest.mark.parametrize("name", ["pallas", "vesta"])
+def test_small_resident_keys_take_the_nibble_table_path(name, gpu_lib, cref):
+    """Keys of at most 1024 points with pre-shifted tables (bucket_groups = 1) are served from nibble tables (k_small_msm:
+    no sort, no buckets): every size from one point (CE::commit, src/backend/commitment.rs:349-361,422,430) to the
+    cap_prove sizes (commitment.rs:261-268), prefixes, both scalar conventions, edge scalars, identity and duplicate
+    bases, and the commitment with a blind v*G + b*H as reef_msm_rows(rows = 1)."""
+    from reef_amd import msm
+    cid = CID[name]
+    C = CURVES[name]
+    rng = SplitMix64(2024 + cid)
+    h = cref.gen_bases_ap(cid, 0xB11D, 1, 1)[0].copy()
+    h2 = cref.gen_bases_ap(cid, 0xB11E, 1, 1)[0].copy()
+    for n in (1, 2, 3, 8, 9, 63, 64, 65, 130, 600, 1024):
+        bases = cref.gen_bases_ap(cid, 31 + n, 7, n)
+        if n >= 8:
+            bases[5] = 0                      # identity base
+            bases[6] = bases[4]               # duplicate: equal table entries meet in the lane tree (P + P)
+            bases[7] = np.frombuffer(C.affine_to_bytes(C.neg(C.affine_from_bytes(bases[4].tobytes()))), dtype=np.uint64)
+        with msm.MsmContext(cid, bases, bucket_groups=1) as ctx:
+            for kind in (0, 1):
+                sc = cref.gen_scalars(cid, 7 * n + kind, n, kind=kind)
+                assert msm.compress(cid, ctx.msm(sc)) == cref.compress(cid, cref.msm_pippenger(cid, bases, sc, threads=2)), (n, kind)
+            canon = np.array([limbs(v) for v in ([0, 1, C.order - 1, 15, 16, (1 << 252) + 5] * n)[:n]], dtype=np.uint64)
+            if n >= 8:
+                canon[4] = canon[6] = canon[7] = limbs(0x1234567)    # s*P + s*P + s*(-P)
+            exp = cref.compress(cid, cref.msm_pippenger(cid, bases, canon, mont=False, threads=2))
+            assert msm.compress(cid, ctx.msm(canon, is_mont=False)) == exp, n
+            m = max(1, n // 2)
+            sc = cref.gen_scalars(cid, 99, m)
+            assert msm.compress(cid, ctx.msm(sc)) == cref.compress(cid, cref.msm_pippenger(cid, bases[:m].copy(), sc, threads=2)), ("prefix", n)
+            dsc = msm.DeviceBuffer.from_host(sc)
+            dout = msm.DeviceBuffer(96)
+            ctx.msm(dsc, m, out=dout)                        # device in, device out: nothing but launches
+            ctx.sync()
+            assert msm.compress(cid, dout.to_host((1, 12))) == cref.compress(cid, cref.msm_pippenger(cid, bases[:m].copy(), sc, threads=2))
+            # v*G + b*H: the commitment with a blind, twice with one generator (cached table) and once with another
+            for hh, seed in ((h, 1), (h, 2), (h2, 3)):
+                v = cref.gen_scalars(cid, 500 + seed, n)
+                b = cref.gen_scalars(cid, 600 + seed, 1)
+                want = cref.compress(cid, cref.row_msm(cid, bases, v, 1, n, h=hh, blinds=b, threads=2))
+                assert msm.compress(cid, ctx.msm_rows(v, 1, n, blinds=b, h=hh)) == want, (n, seed)
+            assert (ctx.msm(np.zeros((0, 4), dtype=np.uint64)) == 0).all()
+    # many rows with blinds: the blind terms come from H's nibble table too (k_add_blind_tab)
+    rows, row_len = 37, 200
+    bases = cref.gen_bases_ap(cid, 77, 13, row_len)
+    sc = cref.gen_scalars(cid, 31337, rows * row_len, kind=2, small_bound=131)
+    bl = cref.gen_scalars(cid, 4, rows)
+    bl[3] = 0
+    with msm.MsmContext(cid, bases) as ctx:
+        assert msm.compress(cid, ctx.msm_rows(sc, rows, row_len, blinds=bl, h=h)) == cref.compress(cid, cref.row_msm(cid, bases, sc, rows, row_len, h=h, blinds=bl, threads=4))
+
+
 @pytest.mark.parametrize("name,logn,kind,groups", [("pallas", 20, 0, 0), ("pallas", 20, 1, 0), ("vesta", 18, 0, 0),
                                                    ("pallas", 18, 0, 1), ("vesta", 17, 1, 1),
                                                    ("pallas", 20, 0, 1), ("pallas", 20, 1, 1)])   # the last two: bench.py's plan
