@@ -15,6 +15,13 @@
 //   consistency      IPA of the Hyrax row length (prove_eval, commitment.rs:371/383)
 // and, beside the MSMs: the Hyrax commitment of the document (--commit), one nlookup sum-check per
 // folding step (rows N2) and the document polynomial's row binding at proof end (row N3).
+//
+// What crosses PCIe: the per-step scalar vectors live in ordinary HOST memory, as nova hands them over
+// (framework.rs:668), and every commitment comes back to the host.  What is checked: the generators are an
+// arithmetic progression B_i = (k0 + i*d)*G, so each MSM has a known discrete logarithm; every per-step
+// commitment is compared with (sum_i s_i*(k0 + i*d) mod r)*G computed from host big-integer arithmetic and a
+// one-point key, and the replay aborts on the first mismatch.  The sizes are PREDICTIONS of Reef's cost model
+// (src/backend/costs.rs restated in SURVEY.md 8), not measurements of a Reef run: flagged in the JSON line.
 // Build: g++ -O2 -std=c++17 reef_replay.cpp -I../../../include -L../../_lib -lreef_msm -o reef_replay
 #include <chrono>
 #include <cstdio>
@@ -33,6 +40,55 @@
 
 using clk = std::chrono::steady_clock;
 static double ms_since(clk::time_point t0) { return std::chrono::duration<double, std::milli>(clk::now() - t0).count(); }
+
+// ---- host-side check: discrete logarithm of an MSM over generators in arithmetic progression ------------------
+static const uint64_t ORDER[2][4] = {   // group orders: Pallas (= Fq), Vesta (= Fp); little-endian limbs
+    {0x8c46eb2100000001ULL, 0x224698fc0994a8ddULL, 0x0ULL, 0x4000000000000000ULL},
+    {0x992d30ed00000001ULL, 0x224698fc094cf91bULL, 0x0ULL, 0x4000000000000000ULL}};
+struct Big { uint64_t w[8] = {0, 0, 0, 0, 0, 0, 0, 0}; };
+static void big_addmul(Big &a, const uint64_t s[4], uint64_t m) {   // a += s * m
+    unsigned __int128 carry = 0;
+    for (int i = 0; i < 8; ++i) {
+        unsigned __int128 t = (unsigned __int128)a.w[i] + carry + (i < 4 ? (unsigned __int128)s[i] * m : 0);
+        a.w[i] = (uint64_t)t;
+        carry = t >> 64;
+    }
+}
+static int big_cmp_shifted(const Big &a, const uint64_t r[4], int shift) {   // a <=> r << shift
+    Big b;
+    const int ws = shift / 64, bs = shift % 64;
+    for (int i = 0; i < 4; ++i) {
+        if (i + ws < 8) b.w[i + ws] |= r[i] << bs;
+        if (bs && i + ws + 1 < 8) b.w[i + ws + 1] |= r[i] >> (64 - bs);
+    }
+    for (int i = 7; i >= 0; --i)
+        if (a.w[i] != b.w[i]) return a.w[i] < b.w[i] ? -1 : 1;
+    return 0;
+}
+static void big_sub_shifted(Big &a, const uint64_t r[4], int shift) {
+    Big b;
+    const int ws = shift / 64, bs = shift % 64;
+    for (int i = 0; i < 4; ++i) {
+        if (i + ws < 8) b.w[i + ws] |= r[i] << bs;
+        if (bs && i + ws + 1 < 8) b.w[i + ws + 1] |= r[i] >> (64 - bs);
+    }
+    unsigned __int128 borrow = 0;
+    for (int i = 0; i < 8; ++i) {
+        unsigned __int128 t = (unsigned __int128)a.w[i] - b.w[i] - borrow;
+        a.w[i] = (uint64_t)t;
+        borrow = (t >> 64) & 1;
+    }
+}
+// (sum_i canon[i] * (k0 + i*d)) mod r as a canonical 4-limb scalar
+static reef_fe dlog_of_msm(int curve, const reef_fe *canon, size_t n, uint64_t k0, uint64_t d) {
+    Big acc;
+    for (size_t i = 0; i < n; ++i) big_addmul(acc, canon[i].l, k0 + (uint64_t)i * d);
+    for (int shift = 511 - 255; shift >= 0; --shift)
+        if (big_cmp_shifted(acc, ORDER[curve], shift) >= 0) big_sub_shifted(acc, ORDER[curve], shift);
+    reef_fe r;
+    for (int i = 0; i < 4; ++i) r.l[i] = acc.w[i];
+    return r;
+}
 
 struct Shape {
     const char *name;
@@ -58,7 +114,23 @@ struct Curve {
     reef_msm_ctx *ipa[2] = {nullptr, nullptr};  // plain contexts re-keyed every IPA round
     reef_affine *d_gens = nullptr;    // device copy of the key for the IPA
     size_t n = 0;
+    uint64_t k0 = 0, d = 0;           // generators B_i = (k0 + i*d)*G
+    reef_msm_ctx *one = nullptr;      // the one-point key [G]: turns an expected discrete logarithm into a point
 };
+static int g_checked = 0;
+// abort unless `got` is dlog*G (both normalised to affine)
+static void check_point(Curve &c, const reef_jacobian &got, const reef_fe &dlog, const char *what) {
+    reef_jacobian want;
+    CK(reef_msm(c.one, &dlog, 1, REEF_HOST, false, &want, REEF_HOST));
+    reef_jacobian both[2] = {got, want};
+    reef_affine aff[2];
+    CK(reef_normalize(c.id, both, 2, REEF_HOST, aff, nullptr));
+    if (memcmp(&aff[0], &aff[1], sizeof(reef_affine)) != 0) {
+        fprintf(stderr, "reef_replay: %s on curve %d differs from its discrete-logarithm closed form\n", what, c.id);
+        exit(4);
+    }
+    ++g_checked;
+}
 
 static size_t next_pow2(size_t x) { size_t p = 1; while (p < x) p <<= 1; return p; }
 
@@ -195,8 +267,17 @@ int main(int argc, char **argv) {
     for (Curve &c : cv) {
         c.d_gens = (reef_affine *)reef_device_alloc(c.n * sizeof(reef_affine));
         auto t0 = clk::now();
-        CK(reef_gen_bases(c.id, 0xC0FFEE + c.id, 7, c.n, c.d_gens, REEF_DEVICE));
+        c.k0 = 0xC0FFEE + c.id; c.d = 7;
+        CK(reef_gen_bases(c.id, c.k0, c.d, c.n, c.d_gens, REEF_DEVICE));
         const double gen_ms = ms_since(t0);
+        {
+            reef_affine g1;
+            CK(reef_gen_bases(c.id, 1, 0, 1, &g1, REEF_HOST));           // 1*G
+            reef_msm_opts og = {};
+            og.bucket_groups = 1;
+            og.device = -1;
+            CK(reef_msm_ctx_create(&c.one, c.id, &g1, 1, REEF_HOST, &og));
+        }
         reef_msm_opts o = {};
         o.bucket_groups = 1;  // commitment keys are fixed for the life of PublicParams: pre-shift once
         o.device = -1;
@@ -218,25 +299,47 @@ int main(int argc, char **argv) {
     // witness-like scalars for W, uniform for the cross terms T
     reef_fe *sW1 = device_scalars(REEF_PALLAS, 11, 1, cv[0].n), *sT1 = device_scalars(REEF_PALLAS, 12, 0, cv[0].n);
     reef_fe *sW2 = device_scalars(REEF_VESTA, 13, 1, cv[1].n), *sT2 = device_scalars(REEF_VESTA, 14, 0, cv[1].n);
+    // the same vectors in HOST memory (Montgomery form, what nova holds) and as canonical integers (for the check)
+    struct HostVec { std::vector<reef_fe> mont, canon; };
+    auto host_vec = [&](int curve, uint64_t seed, int kind, size_t n) {
+        HostVec v;
+        v.mont.resize(n); v.canon.resize(n);
+        CK(reef_gen_scalars(curve, seed, kind, 0, n, true, v.mont.data(), REEF_HOST));
+        CK(reef_gen_scalars(curve, seed, kind, 0, n, false, v.canon.data(), REEF_HOST));
+        return v;
+    };
+    HostVec hW1 = host_vec(REEF_PALLAS, 11, 1, cv[0].n), hT1 = host_vec(REEF_PALLAS, 12, 0, cv[0].n);
+    HostVec hW2 = host_vec(REEF_VESTA, 13, 1, cv[1].n), hT2 = host_vec(REEF_VESTA, 14, 0, cv[1].n);
+    // expected discrete logarithms of the four per-step commitments (computed once, outside the timed loops)
+    const reef_fe eW1 = dlog_of_msm(0, hW1.canon.data(), sh->w1, cv[0].k0, cv[0].d), eT1 = dlog_of_msm(0, hT1.canon.data(), sh->c1, cv[0].k0, cv[0].d);
+    const reef_fe eW2 = dlog_of_msm(1, hW2.canon.data(), sh->w2, cv[1].k0, cv[1].d), eT2 = dlog_of_msm(1, hT2.canon.data(), sh->c2, cv[1].k0, cv[1].d);
 
     reef_jacobian out;
-    auto msm = [&](Curve &c, const reef_fe *s, size_t n) {
-        CK(reef_msm(c.key, s, n, REEF_DEVICE, true, &out, REEF_HOST));   // result to host: it feeds the next circuit
+    auto msm = [&](Curve &c, const HostVec &s, size_t n) {
+        CK(reef_msm(c.key, s.mont.data(), n, REEF_HOST, true, &out, REEF_HOST));   // host scalars in, commitment back to the host: it feeds the next circuit
     };
-    // warm-up (workspace allocation)
-    msm(cv[0], sW1, sh->w1); msm(cv[1], sW2, sh->w2);
+    // warm-up (workspace allocation) and the first check
+    msm(cv[0], hW1, sh->w1); check_point(cv[0], out, eW1, "comm_W1");
+    msm(cv[1], hW2, sh->w2); check_point(cv[1], out, eW2, "comm_W2");
 
     auto t_steps = clk::now();
     std::vector<double> step_ms;
     for (int i = 0; i < sh->steps; ++i) {
         auto ts = clk::now();
-        msm(cv[1], sT2, sh->c2);
-        msm(cv[0], sW1, sh->w1);
-        msm(cv[0], sT1, sh->c1);
-        msm(cv[1], sW2, sh->w2);
+        reef_jacobian o[4];
+        msm(cv[1], hT2, sh->c2); o[0] = out;
+        msm(cv[0], hW1, sh->w1); o[1] = out;
+        msm(cv[0], hT1, sh->c1); o[2] = out;
+        msm(cv[1], hW2, sh->w2); o[3] = out;
         step_ms.push_back(ms_since(ts));
+        check_point(cv[1], o[0], eT2, "comm_T2");           // outside the step's timing
+        check_point(cv[0], o[1], eW1, "comm_W1");
+        check_point(cv[0], o[2], eT1, "comm_T1");
+        check_point(cv[1], o[3], eW2, "comm_W2");
     }
-    const double steps_ms = ms_since(t_steps);
+    double steps_ms = 0;
+    for (double v : step_ms) steps_ms += v;
+    (void)t_steps;
 
     // The same commitments with the two of each curve issued as ONE batched call (comm_W and comm_T of a
     // step are both absorbed before the folding challenge is drawn, so neither needs the other): rows = 2
@@ -246,22 +349,30 @@ int main(int argc, char **argv) {
     {
         struct Pair { Curve *c; const reef_fe *a, *b; size_t len; reef_fe *buf; } pairs[2] = {
             {&cv[0], sW1, sT1, sh->w1 > sh->c1 ? sh->w1 : sh->c1, nullptr}, {&cv[1], sW2, sT2, sh->w2 > sh->c2 ? sh->w2 : sh->c2, nullptr}};
-        for (Pair &p : pairs) {
-            p.buf = (reef_fe *)reef_device_alloc(2 * p.len * sizeof(reef_fe));
-            CK(reef_memcpy(p.buf, p.a, p.len * sizeof(reef_fe), REEF_DEVICE, REEF_DEVICE));
-            CK(reef_memcpy(p.buf + p.len, p.b, p.len * sizeof(reef_fe), REEF_DEVICE, REEF_DEVICE));
+        std::vector<reef_fe> hostbuf[2];
+        const HostVec *hv[2][2] = {{&hW1, &hT1}, {&hW2, &hT2}};
+        reef_fe expect[2][2];
+        for (int k = 0; k < 2; ++k) {
+            Pair &p = pairs[k];
+            hostbuf[k].resize(2 * p.len);                // the two vectors of a curve side by side in host memory
+            memcpy(hostbuf[k].data(), hv[k][0]->mont.data(), p.len * sizeof(reef_fe));
+            memcpy(hostbuf[k].data() + p.len, hv[k][1]->mont.data(), p.len * sizeof(reef_fe));
+            for (int j = 0; j < 2; ++j) expect[k][j] = dlog_of_msm(k, hv[k][j]->canon.data(), p.len, p.c->k0, p.c->d);
         }
         reef_jacobian two[2];
-        auto both = [&](Pair &p) { CK(reef_msm_rows(p.c->key, p.buf, 2, p.len, REEF_DEVICE, true, 255, nullptr, nullptr, two, REEF_HOST)); };
-        both(pairs[0]); both(pairs[1]);   // warm-up
+        auto both = [&](int k) { CK(reef_msm_rows(pairs[k].c->key, hostbuf[k].data(), 2, pairs[k].len, REEF_HOST, true, 255, nullptr, nullptr, two, REEF_HOST)); };
+        for (int k = 0; k < 2; ++k) {                    // warm-up and check
+            both(k);
+            check_point(*pairs[k].c, two[0], expect[k][0], "batched comm_W");
+            check_point(*pairs[k].c, two[1], expect[k][1], "batched comm_T");
+        }
         auto tb = clk::now();
-        for (int i = 0; i < sh->steps; ++i) { both(pairs[1]); both(pairs[0]); }
+        for (int i = 0; i < sh->steps; ++i) { both(1); both(0); }
         steps_batched_ms = ms_since(tb);
-        for (Pair &p : pairs) reef_device_free(p.buf);
     }
 
     auto t_final = clk::now();
-    msm(cv[1], sT2, sh->c2);  // last NIFS fold
+    msm(cv[1], hT2, sh->c2);  // last NIFS fold
     int r1 = 0, r2 = 0, r3 = 0;
     const double ipa1_ms = nofold ? run_ipa_nofold(cv[0], cv[0].n, sT1, &r1) : run_ipa(cv[0], cv[0].n, sT1, &r1);
     const double ipa2_ms = nofold ? run_ipa_nofold(cv[1], cv[1].n, sT2, &r2) : run_ipa(cv[1], cv[1].n, sT2, &r2);
@@ -321,16 +432,19 @@ int main(int argc, char **argv) {
 
     const size_t pairs_step = sh->c2 + sh->w1 + sh->c1 + sh->w2;
     printf("{\"replay\": \"%s\", \"ipa\": \"%s\", \"note\": \"MSM work of reef --prove replayed through the C ABI; host-side proving work not included\", "
+           "\"shapes\": \"PREDICTED by Reef's cost model (src/backend/costs.rs as restated in SURVEY.md 8), not measured on a Reef run\", "
+           "\"scalars\": \"per-step vectors in host memory, commitments returned to the host (PCIe inclusive)\", \"commitments_checked_against_dlog\": %d, "
            "\"key_pallas\": %zu, \"key_vesta\": %zu, \"steps\": %d, \"setup_ms\": %.3f, \"fold_steps_ms\": %.3f, \"ms_per_step\": %.3f, "
            "\"ms_per_step_batched_pairs\": %.3f, \"pairs_per_step\": %zu, \"final_snark_ms\": %.3f, \"ipa_pallas_ms\": %.3f, \"ipa_pallas_rounds\": %d, \"ipa_vesta_ms\": %.3f, "
            "\"ipa_vesta_rounds\": %d, \"consistency_ipa_ms\": %.3f, \"consistency_rounds\": %d, \"total_prove_msm_ms\": %.3f, "
            "\"commit_hyrax_ms\": %.3f, \"commit_hyrax_first_call_ms\": %.3f, \"sumcheck_table_log\": %d, \"sumcheck_ms_per_step\": %.3f, "
            "\"doc_poly_bind_rows_ms\": %.3f, \"total_prove_gpu_ms\": %.3f}\n",
-           sh->name, nofold ? "cross terms over the original key (no generator fold)" : "generator fold per round", cv[0].n, cv[1].n, sh->steps, setup_ms, steps_ms, steps_ms / sh->steps, steps_batched_ms / sh->steps, pairs_step, final_ms, ipa1_ms, r1, ipa2_ms, r2,
+           sh->name, nofold ? "cross terms over the original key (no generator fold)" : "generator fold per round", g_checked, cv[0].n, cv[1].n, sh->steps, setup_ms, steps_ms, steps_ms / sh->steps, steps_batched_ms / sh->steps, pairs_step, final_ms, ipa1_ms, r1, ipa2_ms, r2,
            cons_ms, r3, steps_ms + final_ms + cons_ms, commit_ms, commit_first_ms, sh->table_log, sc_step_ms, mle_ms,
            steps_ms + final_ms + cons_ms + sh->steps * sc_step_ms + mle_ms);
     for (Curve &c : cv) {
         reef_msm_ctx_destroy(c.key);
+        reef_msm_ctx_destroy(c.one);
         for (auto &x : c.ipa) reef_msm_ctx_destroy(x);
         reef_device_free(c.d_gens);
     }

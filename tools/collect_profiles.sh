@@ -1,0 +1,31 @@
+#!/bin/bash
+# On the MI355X box: everything profiles/ holds for a round.  usage: tools/collect_profiles.sh OUTDIR [rNN]
+out=$(realpath -m $1); R=${2:-r02}; export REEF_ROUND=$R
+mkdir -p $out; export TMPDIR=/tmp; root=$GRAFT_REPO_ROOT
+python $root/bench.py --steps 20 --warmup 5 > $out/${R}_bench.json 2> $out/${R}_bench.err
+(cd /tmp && rm -rf /tmp/ks && rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/ks -- python $root/bench.py --steps 20 --warmup 5 --no-cpu-baseline > /dev/null 2>&1; cp /tmp/ks/*/*kernel_stats.csv $out/${R}_kernel_stats.csv)
+python $root/tools/pmc_traffic.py $out > $out/${R}_pmc_traffic.log 2>&1
+python $root/tools/pmc_valu.py $out/${R}_pmc_valu_issue.json > /dev/null 2>&1
+python $root/tools/sweep_plans.py 12 14 15 16 17 18 20 2>&1 | grep "##" > $out/${R}_latency_sweep.txt
+python $root/tools/time_small.py > $out/${R}_small_msm_latency.txt 2>&1
+(python $root/tools/time_host_combine.py; REEF_MSM_HOST_COMBINE=0 python $root/tools/time_host_combine.py) > $out/${R}_host_combine.txt 2>&1
+for c in cfg1 cfg3 cfg4 cfg5; do $root/reef_amd/_lib/reef_replay $c nofold; done > $out/${R}_replay_prove_msm.jsonl 2>/dev/null
+$root/reef_amd/_lib/reef_replay cfg3 >> $out/${R}_replay_prove_msm.jsonl 2>/dev/null
+$root/reef_amd/_lib/reef_replay cfg4 >> $out/${R}_replay_prove_msm.jsonl 2>/dev/null
+for cfg in "15 13 1" "16 15 1" "20 17 1"; do $root/tools/prof_cfg.sh /tmp/tr $cfg 0 both; done
+cat /tmp/tr/trace_*.txt > $out/${R}_msm_kernel_timelines.txt
+(cd /tmp && rm -rf /tmp/pp && rocprofv3 --kernel-trace --output-format csv -d /tmp/pp -- python $root/tools/coop_probe.py > /dev/null 2>&1; python - <<PY > $out/${R}_group_op_latency.txt
+import csv, glob
+rows = list(csv.DictReader(open(glob.glob('/tmp/pp/*/*kernel_trace.csv')[0])))
+rows = [r for r in rows if 'k_test_ec' in r['Kernel_Name']][-4:]
+names = ['four-wave addition x256', 'four-wave doubling x64', 'one-wave addition x128', 'one-wave doubling x64']
+cnt = [256, 64, 128, 64]
+print('# tools/coop_probe.py under rocprofv3 --kernel-trace: chained group operations on ONE workgroup, us per operation')
+for r, n, c in zip(rows, names, cnt):
+    d = (int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3
+    print(f'{n:28s} {d:9.1f} us total  {d / c:6.2f} us per operation')
+PY
+)
+python $root/tools/time_rows.py 1024 2048 131 > $out/${R}_rows_timing.txt 2>&1; python $root/tools/time_rows.py 4096 8192 7 >> $out/${R}_rows_timing.txt 2>&1
+python $root/tools/time_sumcheck.py 21 26 > $out/${R}_sumcheck_timing.txt 2>&1
+python $root/tools/time_mle.py > $out/${R}_mle_timing.txt 2>&1

@@ -5,8 +5,8 @@ Runs `bench.py` twice under `rocprofv3 --pmc <counter> --kernel-trace` (FETCH_SI
 separate passes, never combined with any other trace domain), condenses the counter_collection CSVs
 to one line per dispatch and writes profiles-ready files:
 
-    <out>/r01_pmc_FETCH_SIZE_bench_counters.csv, <out>/r01_pmc_WRITE_SIZE_bench_counters.csv
-    <out>/r01_pmc_traffic.json      average bytes per launch per kernel
+    <out>/rNN_pmc_FETCH_SIZE_bench_counters.csv, <out>/rNN_pmc_WRITE_SIZE_bench_counters.csv
+    <out>/rNN_pmc_traffic.json      average bytes per launch per kernel
 
 Units: both counters are reported in KiB.  Correction factors (see the _comment in the JSON): on
 this part FETCH_SIZE counts a coalesced stream at half its size and a 64-byte-granular gather at
@@ -23,6 +23,7 @@ import sys
 from collections import defaultdict
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+RND = os.environ.get("REEF_ROUND", "r02")      # file prefix: profiles are named per round
 outdir = os.path.abspath(sys.argv[1])
 bench_args = sys.argv[2:] or ["--steps", "4", "--warmup", "1", "--no-cpu-baseline", "--streams", "1"]
 os.makedirs(outdir, exist_ok=True)
@@ -52,7 +53,7 @@ for counter in ("FETCH_SIZE", "WRITE_SIZE"):
         if r["Counter_Name"] == counter:
             vals[r["Dispatch_Id"]] += float(r["Counter_Value"])
             names[r["Dispatch_Id"]] = short(r["Kernel_Name"])
-    with open(os.path.join(outdir, f"r01_pmc_{counter}_bench_counters.csv"), "w", newline="") as f:
+    with open(os.path.join(outdir, f"{RND}_pmc_{counter}_bench_counters.csv"), "w", newline="") as f:
         w = csv.writer(f)
         w.writerow(["Kernel", "Dispatch_Id", "Counter", "Value_KiB", "DurationNs"])
         for did in sorted(vals, key=int):
@@ -79,5 +80,5 @@ json.dump({
     "config": {"curve": "pallas", "logn": cfg["points_per_gpu"].bit_length() - 1, "window_bits": cfg["window_bits"],
                "bucket_groups": cfg["bucket_groups"]},
     "kernels": kernels,
-}, open(os.path.join(outdir, "r01_pmc_traffic.json"), "w"), indent=1)
+}, open(os.path.join(outdir, f"{RND}_pmc_traffic.json"), "w"), indent=1)
 print(json.dumps({k: round(v["hbm_bytes_per_launch"] / 1e6, 1) for k, v in kernels.items()}))

@@ -38,6 +38,6 @@ for g in GROUPS:
     for name, cs in acc.items():
         for c, v in cs.items():
             res[name][c] = sum(v) / len(v)
-out = {k: v for k, v in res.items() if k.startswith(("k_accum0", "k_accumN", "k_scatter", "k_count", "k_reduce"))}
+out = {k: v for k, v in res.items() if k.startswith(("k_accum0", "k_accumN", "k_merge", "k_scatter", "k_count", "k_reduce", "k_fine"))}
 json.dump(out, open(sys.argv[1], "w"), indent=1)
 print(json.dumps(out.get("k_accum0<0>", {}), indent=1))
