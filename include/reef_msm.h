@@ -237,6 +237,36 @@ reef_status reef_mle_bound_rows(int curve, const void *z, size_t n, int elem_byt
                                 reef_fe *eval_out);
 
 /* ---------------------------------------------------------------------------------------------
+ * (3d) Row N4: the Poseidon Merkle commitment of the document (`--merkle`).
+ *
+ * Replaces MerkleCommitment::new(&doc, &pc) (src/backend/merkle_tree.rs:25-80, new_parent :82-114; built at
+ * src/backend/commitment.rs:94-100) over the SCALAR field of `curve` (Reef: REEF_PALLAS, G1::Scalar):
+ *   level 0, node i = H4(2i, doc[2i], 2i+1, doc[2i+1])      an odd last symbol hashes (2i, doc[2i], 0, 0)
+ *   level h, node i = H2(below[2i], below[2i+1])             an odd last node hashes (below[2i], 0)
+ *   H_k(x_1..x_k)   = P([tag_k, x_1, .., x_k, 0, ..])[1]     P = the Poseidon permutation of width 5 (x^5 S-box,
+ *                     full_rounds/2 full rounds, partial_rounds partial rounds, full_rounds/2 full rounds; a round adds
+ *                     the round constants, applies the S-box and multiplies by the MDS matrix)
+ * which is what neptune's Sponge<F, U4> in Mode::Simplex computes for IOPattern [Absorb(k), Squeeze(1)] [R].  The
+ * constants are the CALLER'S: round_constants, mds and the two tags are neptune's PoseidonConstants fields and the
+ * domain tags its sponge API derives from the two IO patterns -- that crate is not in the reference tree, so nothing
+ * here restates it.  All field elements (constants in, tree out) are canonical integers, or in the pasta Montgomery
+ * form when is_mont.  `doc`: one 32-bit value per document symbol (the indices of framework.rs:978-1011).
+ * tree_out (may be NULL): all levels, level 0 first, reef_merkle_nodes(n) elements; root_out (host, may be NULL). */
+typedef struct {
+    uint32_t width;              /* state width t = arity + 1; only 5 (Reef's U4) is built */
+    uint32_t full_rounds;        /* R_F, even */
+    uint32_t partial_rounds;     /* R_P */
+    uint32_t reserved;
+    const reef_fe *round_constants; /* host: width * (R_F + R_P) elements, round-major */
+    const reef_fe *mds;          /* host: width * width; new[j] = sum_i state[i] * mds[i*width + j] */
+    reef_fe tag_leaf;            /* state[0] of the 4-input leaf hash */
+    reef_fe tag_node;            /* state[0] of the 2-input node hash */
+} reef_poseidon_params;
+uint64_t reef_merkle_nodes(uint64_t n);
+reef_status reef_merkle_commit(int curve, const reef_poseidon_params *params, const uint32_t *doc, size_t n, int doc_loc,
+                               bool is_mont, reef_fe *tree_out, int tree_loc, reef_fe *root_out);
+
+/* ---------------------------------------------------------------------------------------------
  * (4) Runtime plumbing.
  * ------------------------------------------------------------------------------------------- */
 int reef_device_count(void);

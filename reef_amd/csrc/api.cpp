@@ -282,6 +282,23 @@ reef_status reef_sc_sync(reef_sc_ctx *ctx) {
     return vt(ctx->curve)->sc_sync(ctx->impl);
 }
 
+uint64_t reef_merkle_nodes(uint64_t n) {
+    uint64_t total = 0, m = (n + 1) / 2;
+    for (;;) {
+        total += m;
+        if (m <= 1) break;
+        m = (m + 1) / 2;
+    }
+    return total;
+}
+reef_status reef_merkle_commit(int curve, const reef_poseidon_params *params, const uint32_t *doc, size_t n, int doc_loc, bool is_mont,
+                               reef_fe *tree_out, int tree_loc, reef_fe *root_out) {
+    const CurveVTable *v = vt(curve);
+    if (!v) return REEF_ERR_ARG;
+    REEF_TRY(require_gpu());
+    return v->merkle_commit(params, doc, n, doc_loc, is_mont, tree_out, tree_loc, root_out);
+}
+
 // ---- pasta-msm drop-in symbols: stateless, abort on failure (the Rust side panics on error).
 // A per-thread context is kept so that repeated calls reuse the workspace; the bases are
 // re-uploaded on every call, as the reference semantics (nothing retained) require.

@@ -88,6 +88,9 @@ struct CurveVTable {
     // row N3: bound rows / evaluation of a multilinear table over the curve's scalar field
     reef_status (*mle_bound)(const void *z, size_t n, int elem_bytes, int z_loc, bool is_mont, const reef_fe *point, size_t num_vars,
                              size_t left_vars, reef_fe *lz_out, int out_loc, reef_fe *eval_out);
+    // row N4: Poseidon Merkle commitment over the curve's scalar field
+    reef_status (*merkle_commit)(const reef_poseidon_params *pp, const uint32_t *doc, size_t n, int doc_loc, bool is_mont, reef_fe *tree_out,
+                                 int out_loc, reef_fe *root_out);
     reef_status (*fingerprint)(const void *dev, size_t bytes, uint64_t out[2]);
     reef_status (*bytes_equal)(const void *dev_a, const void *dev_b, size_t bytes, int *equal);
     reef_status (*plan_for)(size_t n, uint32_t c_opt, uint32_t g_opt, uint32_t *c, uint32_t *w, uint32_t *g, uint32_t *t);

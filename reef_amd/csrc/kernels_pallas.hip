@@ -3,6 +3,7 @@
 #include "msm_kernels.inc"
 #include "sumcheck_kernels.inc"
 #include "mle_kernels.inc"
+#include "merkle_kernels.inc"
 #include "engine.inc"
 namespace reef {
 const CurveVTable *pallas_vtable() {

@@ -1,0 +1,49 @@
+"""Row N4: the Poseidon Merkle commitment of the document (`--merkle`, src/backend/merkle_tree.rs:25-114) through the
+C ABI (reef_merkle_commit).  The Poseidon constants and the two domain tags are the caller's (neptune's, on the Rust
+side); this module only marshals them."""
+from __future__ import annotations
+
+import ctypes
+from typing import List, Sequence, Tuple
+
+import numpy as np
+
+from . import _ffi
+from ._ffi import REEF_HOST, check
+from .msm import curve_id
+from .sumcheck import array_to_ints, ints_to_array
+
+
+class PoseidonParams(ctypes.Structure):
+    _fields_ = [("width", ctypes.c_uint32), ("full_rounds", ctypes.c_uint32), ("partial_rounds", ctypes.c_uint32), ("reserved", ctypes.c_uint32),
+                ("round_constants", ctypes.c_void_p), ("mds", ctypes.c_void_p), ("tag_leaf", ctypes.c_uint64 * 4), ("tag_node", ctypes.c_uint64 * 4)]
+
+
+def nodes(n: int) -> int:
+    return _ffi.load().reef_merkle_nodes(n)
+
+
+def commit(curve, doc: Sequence[int], width: int, full_rounds: int, partial_rounds: int, round_constants: Sequence[int],
+           mds: Sequence[Sequence[int]], tag_leaf: int, tag_node: int) -> Tuple[int, List[List[int]]]:
+    """-> (commitment, tree levels) as integers; inputs as integers (canonical)."""
+    lib = _ffi.load()
+    rc = ints_to_array(list(round_constants))
+    m = ints_to_array([x for row in mds for x in row])
+    pp = PoseidonParams(width, full_rounds, partial_rounds, 0, rc.ctypes.data, m.ctypes.data,
+                        (ctypes.c_uint64 * 4)(*[(tag_leaf >> (64 * i)) & 0xFFFFFFFFFFFFFFFF for i in range(4)]),
+                        (ctypes.c_uint64 * 4)(*[(tag_node >> (64 * i)) & 0xFFFFFFFFFFFFFFFF for i in range(4)]))
+    d = np.ascontiguousarray(np.asarray(doc, dtype=np.uint32))
+    n = d.shape[0]
+    total = nodes(n) if n else 0
+    tree = np.zeros((max(total, 1), 4), dtype=np.uint64)
+    root = np.zeros((1, 4), dtype=np.uint64)
+    check(lib.reef_merkle_commit(curve_id(curve), ctypes.byref(pp), d.ctypes.data, n, REEF_HOST, False, tree.ctypes.data, REEF_HOST, root.ctypes.data))
+    flat = array_to_ints(tree[:total])
+    levels, m_, off = [], (n + 1) // 2, 0
+    while True:
+        levels.append(flat[off:off + m_])
+        off += m_
+        if m_ <= 1:
+            break
+        m_ = (m_ + 1) // 2
+    return array_to_ints(root)[0], levels

@@ -1,0 +1,63 @@
+"""Row N4 on the GPU: the Poseidon Merkle tree of reef_merkle_commit against the oracle, node for node, with the
+caller-supplied constants (stand-ins here; neptune's on the Rust side)."""
+import numpy as np
+import pytest
+
+from oracle import merkle_oracle as M
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("n", [1, 2, 3, 7, 8, 100, 1001, 4096])
+def test_tree_matches_oracle(n, gpu_lib):
+    from reef_amd import merkle
+    p = M.standin_params()
+    doc = [(31 * i + 7) % 131 for i in range(n)]
+    root, tree = merkle.commit("pallas", doc, p.t, p.rf, p.rp, p.rc, p.mds, p.tag_leaf, p.tag_node)
+    eroot, etree = M.commit(doc, p)
+    assert tree == etree and root == eroot
+
+
+def test_reference_make_mt_on_gpu(gpu_lib):
+    """merkle_tree.rs:209-257 with the tree built on the GPU: every leaf's path recomputes the commitment."""
+    from reef_amd import merkle
+    p = M.standin_params()
+    doc = [2, 3, 4, 5, 6, 7, 8]
+    root, tree = merkle.commit("pallas", doc, p.t, p.rf, p.rp, p.rc, p.mds, p.tag_leaf, p.tag_node)
+    for q in range(len(doc)):
+        assert M.root_from_path(doc, q, M.path_wits(doc, tree, q), p) == root
+
+
+def test_other_constants_vesta_field_and_errors(gpu_lib):
+    from reef_amd import merkle, msm
+    p = M.standin_params(M.P, 5, 8, 20)                           # another field, other round numbers: nothing is hard-wired
+    p.tag_leaf, p.tag_node = 12345, M.P - 1
+    doc = list(range(50, 77)) + [0xFFFFFFFF]                      # 32-bit symbols
+    root, tree = merkle.commit("vesta", doc, p.t, p.rf, p.rp, p.rc, p.mds, p.tag_leaf, p.tag_node)
+    assert (root, tree) == M.commit(doc, p)
+    with pytest.raises(msm.ReefError):
+        merkle.commit("pallas", [1, 2], 3, 8, 56, p.rc, p.mds, 1, 2)      # only width 5 is built
+    with pytest.raises(msm.ReefError):
+        merkle.commit("pallas", [1, 2], 5, 7, 56, p.rc, p.mds, 1, 2)      # odd number of full rounds
+
+
+def test_large_document_properties(gpu_lib):
+    """2^20 symbols: spot-checked leaves and the whole upper tree against the oracle (the oracle hashes ~2000 nodes here)."""
+    from reef_amd import merkle
+    p = M.standin_params()
+    n = (1 << 20) - 3
+    rng = np.random.default_rng(5)
+    doc = rng.integers(0, 131, size=n, dtype=np.uint32)
+    root, tree = merkle.commit("pallas", doc, p.t, p.rf, p.rp, p.rc, p.mds, p.tag_leaf, p.tag_node)
+    for i in (0, 1, 12345, (n + 1) // 2 - 1):
+        right = [2 * i + 1, int(doc[2 * i + 1])] if 2 * i + 1 < n else [0, 0]
+        assert tree[0][i] == M.hash_query([2 * i, int(doc[2 * i])] + right, p)
+    lvl = 10                                                      # from 1024 nodes up, every node
+    for h in range(lvl, len(tree) - 1):
+        below = tree[h]
+        for i in range(len(tree[h + 1])):
+            r = below[2 * i + 1] if 2 * i + 1 < len(below) else 0
+            assert tree[h + 1][i] == M.hash_query([below[2 * i], r], p)
+    assert tree[-1][0] == root
+    q = 777
+    assert M.root_from_path([int(v) for v in doc[:0]] or doc.tolist(), q, M.path_wits(doc.tolist(), tree, q), p) == root

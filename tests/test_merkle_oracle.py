@@ -1,0 +1,49 @@
+"""Row N4 oracle: the tree of MerkleCommitment::new and the path witnesses, pinned by replaying the reference's own
+test `make_mt` (src/backend/merkle_tree.rs:209-257: document [2..8], every leaf's path recomputes the commitment); the
+property holds for any node hash, so it pins the TREE, not neptune's digests (stand-in constants, see the oracle's header)."""
+from oracle import merkle_oracle as M
+
+
+def test_reference_make_mt_replayed():
+    p = M.standin_params()
+    doc = [2, 3, 4, 5, 6, 7, 8]                                   # the reference's "document"
+    root, tree = M.commit(doc, p)
+    assert [len(l) for l in tree] == [4, 2, 1] and tree[-1][0] == root
+    for q in range(len(doc)):                                     # qs = 0..6 in the reference
+        wits = M.path_wits(doc, tree, q)
+        assert len(wits) == len(tree)
+        assert M.root_from_path(doc, q, wits, p) == root
+    # the four query shapes of new_parent (merkle_tree.rs:87-103)
+    assert tree[0][3] == M.hash_query([6, 8, 0, 0], p)            # odd last leaf: (idx, char, 0, 0)
+    assert tree[0][0] == M.hash_query([0, 2, 1, 3], p)
+    assert tree[1][1] == M.hash_query([tree[0][2], tree[0][3]], p)
+    assert root == M.hash_query([tree[1][0], tree[1][1]], p)
+
+
+def test_odd_levels_and_single_symbols():
+    p = M.standin_params()
+    for n in (1, 2, 3, 5, 6, 9, 17, 100):
+        doc = [(7 * i + 3) % 131 for i in range(n)]
+        root, tree = M.commit(doc, p)
+        m, sizes = (n + 1) // 2, []
+        while True:
+            sizes.append(m)
+            if m <= 1:
+                break
+            m = (m + 1) // 2
+        assert [len(l) for l in tree] == sizes
+        for q in range(n):
+            assert M.root_from_path(doc, q, M.path_wits(doc, tree, q), p) == root
+        for h in range(len(tree) - 1):                            # an odd last node is hashed with zero (merkle_tree.rs:97-99)
+            if len(tree[h]) % 2:
+                assert tree[h + 1][-1] == M.hash_query([tree[h][-1], 0], p)
+
+
+def test_permutation_is_a_permutation_and_sensitive():
+    p = M.standin_params()
+    assert len(p.rc) == 5 * 64 and all(0 <= c < M.Q for c in p.rc) and len(set(p.rc)) == len(p.rc)
+    a = M.poseidon_permute([1, 2, 3, 4, 5], p)
+    b = M.poseidon_permute([1, 2, 3, 4, 6], p)
+    assert a != b and len(set(a)) == 5 and all(0 <= x < M.Q for x in a)
+    # the MDS matrix is invertible (Cauchy): distinct rows, full rank over the field by construction 1/(x_i + y_j)
+    assert all(p.mds[i][j] * (i + 5 + j) % M.Q == 1 for i in range(5) for j in range(5))
