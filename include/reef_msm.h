@@ -267,6 +267,34 @@ reef_status reef_merkle_commit(int curve, const reef_poseidon_params *params, co
                                bool is_mont, reef_fe *tree_out, int tree_loc, reef_fe *root_out);
 
 /* ---------------------------------------------------------------------------------------------
+ * (3e) Row N1: derivation of a commitment key from a label.
+ *
+ * Replaces nova-snark's CommitmentGens::new(label, n) -> from_label [R] (called at PublicParams::setup,
+ * src/backend/framework.rs:297-303, and at SpartanSNARK::setup / HyraxPC::setup, src/backend/commitment.rs:146-149,
+ * 176-180; once per --prove and once per --verify):
+ *   stream  = SHAKE256(label), squeezed into n strings of 32 bytes                    (host: the XOF is sequential)
+ *   out[i]  = hash_to_curve(stream[32 i .. 32 i + 32))                                (GPU: one generator per thread)
+ * hash_to_curve is RFC 9380's: u0, u1 = hash_to_field(msg, 2) with expand_message_xmd over BLAKE2b-512 and 64-byte
+ * strings per element; Q_j = iso_map(map_to_curve_simple_swu(u_j)) through the curve E': y^2 = x^3 + a x + b that is
+ * 3-isogenous to y^2 = x^3 + 5; out = Q_0 + Q_1 (the Pasta curves have cofactor 1).  Everything pasta_curves fixes
+ * and this repository cannot confirm from the reference tree [R] is DATA of the call: a, b, Z of the SWU map, the 13
+ * coefficients of the isogeny (x_num[4], x_den[2], y_num[4], y_den[3]: highest degree first, the monic leading terms
+ * of the denominators left out), the domain separation string and the byte order hash_to_field reads its 64-byte
+ * strings in.  Field elements of the parameters are canonical integers of the curve's BASE field, or pasta
+ * Montgomery form when is_mont.  out: n affine points in the ABI form (identity = (0, 0)), host or device. */
+typedef struct {
+    reef_fe a, b, z;             /* E' and the SWU constant Z (a non-square with g(b/(Z a)) square, RFC 9380 6.6.2) */
+    reef_fe iso[13];             /* x_num[4], x_den[2], y_num[4], y_den[3] */
+    const uint8_t *dst;          /* host: domain separation string, at most 255 bytes */
+    uint32_t dst_len;
+    uint32_t little_endian;      /* 0: OS2IP big-endian strings (RFC 9380 5.2); 1: little-endian */
+} reef_keygen_params;
+reef_status reef_derive_generators(int curve, const uint8_t *label, size_t label_len, size_t n, const reef_keygen_params *params,
+                                   bool is_mont, reef_affine *out, int out_loc);
+/* SHAKE256(in) -> out_len bytes: the host half of the derivation, exported for tests and for callers that want the stream. */
+void reef_shake256(const uint8_t *in, size_t in_len, uint8_t *out, size_t out_len);
+
+/* ---------------------------------------------------------------------------------------------
  * (4) Runtime plumbing.
  * ------------------------------------------------------------------------------------------- */
 int reef_device_count(void);

@@ -101,6 +101,8 @@ def load() -> ctypes.CDLL:
         "reef_sc_sync": (c_int, [vp]),
         "reef_merkle_nodes": (c_uint64, [c_uint64]),
         "reef_merkle_commit": (c_int, [c_int, vp, vp, c_size_t, c_int, c_bool, vp, c_int, vp]),
+        "reef_derive_generators": (c_int, [c_int, vp, c_size_t, c_size_t, vp, c_bool, vp, c_int]),
+        "reef_shake256": (None, [vp, c_size_t, vp, c_size_t]),
         "reef_test_field_op": (c_int, [c_int, c_int, vp, vp, vp, c_size_t]),
         "reef_test_ec_op": (c_int, [c_int, c_int, vp, vp, vp, vp, c_size_t]),
         "reef_bench_fmul": (c_int, [c_int, c_uint32, POINTER(c_double)]),

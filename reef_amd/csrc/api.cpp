@@ -11,6 +11,7 @@
 #include <mutex>
 
 #include "common.h"
+#include "keccak.h"
 
 namespace reef {
 
@@ -298,6 +299,15 @@ reef_status reef_merkle_commit(int curve, const reef_poseidon_params *params, co
     REEF_TRY(require_gpu());
     return v->merkle_commit(params, doc, n, doc_loc, is_mont, tree_out, tree_loc, root_out);
 }
+
+reef_status reef_derive_generators(int curve, const uint8_t *label, size_t label_len, size_t n, const reef_keygen_params *params, bool is_mont,
+                                   reef_affine *out, int out_loc) {
+    const CurveVTable *v = vt(curve);
+    if (!v) return REEF_ERR_ARG;
+    REEF_TRY(require_gpu());
+    return v->derive_generators(label, label_len, n, params, is_mont, out, out_loc);
+}
+void reef_shake256(const uint8_t *in, size_t in_len, uint8_t *out, size_t out_len) { reef::shake256(in, in_len, out, out_len); }
 
 // ---- pasta-msm drop-in symbols: stateless, abort on failure (the Rust side panics on error).
 // A per-thread context is kept so that repeated calls reuse the workspace; the bases are

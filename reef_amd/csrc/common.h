@@ -91,6 +91,9 @@ struct CurveVTable {
     // row N4: Poseidon Merkle commitment over the curve's scalar field
     reef_status (*merkle_commit)(const reef_poseidon_params *pp, const uint32_t *doc, size_t n, int doc_loc, bool is_mont, reef_fe *tree_out,
                                  int out_loc, reef_fe *root_out);
+    // row N1: commitment-key derivation (hash to the curve; coordinates in the curve's base field)
+    reef_status (*derive_generators)(const uint8_t *label, size_t label_len, size_t n, const reef_keygen_params *kp, bool is_mont, reef_affine *out,
+                                     int out_loc);
     reef_status (*fingerprint)(const void *dev, size_t bytes, uint64_t out[2]);
     reef_status (*bytes_equal)(const void *dev_a, const void *dev_b, size_t bytes, int *equal);
     reef_status (*plan_for)(size_t n, uint32_t c_opt, uint32_t g_opt, uint32_t *c, uint32_t *w, uint32_t *g, uint32_t *t);

@@ -4,6 +4,7 @@
 #include "sumcheck_kernels.inc"
 #include "mle_kernels.inc"
 #include "merkle_kernels.inc"
+#include "keygen_kernels.inc"
 #include "engine.inc"
 namespace reef {
 const CurveVTable *vesta_vtable() {
