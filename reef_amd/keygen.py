@@ -10,7 +10,7 @@ from typing import List, Optional, Sequence, Tuple
 import numpy as np
 
 from . import _ffi
-from ._ffi import REEF_HOST, check
+from ._ffi import REEF_DEVICE, REEF_HOST, check
 from .msm import curve_id
 
 Point = Optional[Tuple[int, int]]
@@ -35,12 +35,17 @@ def shake256(data: bytes, out_len: int) -> bytes:
 
 
 def derive_generators(curve, label: bytes, n: int, a: int, b: int, z: int, iso: Sequence[int], dst: bytes,
-                      little_endian: bool = False) -> np.ndarray:
-    """-> (n, 8) uint64: n affine points in the ABI form (what reef_msm_ctx_create takes as a key).  Parameters as canonical
-    integers of the curve's base field."""
+                      little_endian: bool = False, device: bool = False):
+    """-> (n, 8) uint64: n affine points in the ABI form (what reef_msm_ctx_create takes as a key), or with `device` a
+    DeviceBuffer holding them (the key never visits the host).  Parameters as canonical integers of the curve's base field."""
     assert len(iso) == 13
     lib = _ffi.load()
     kp = KeygenParams(_fe(a), _fe(b), _fe(z), ((ctypes.c_uint64 * 4) * 13)(*[_fe(c) for c in iso]), dst, len(dst), 1 if little_endian else 0)
+    if device:
+        from .msm import DeviceBuffer
+        buf = DeviceBuffer(64 * n)
+        check(lib.reef_derive_generators(curve_id(curve), label, len(label), n, ctypes.byref(kp), False, buf.ptr, REEF_DEVICE))
+        return buf
     out = np.zeros((n, 8), dtype=np.uint64)
     check(lib.reef_derive_generators(curve_id(curve), label, len(label), n, ctypes.byref(kp), False, out.ctypes.data, REEF_HOST))
     return out
