@@ -31,27 +31,71 @@ namespace reef {
 
 static constexpr int COOP_SLOTS = 11;
 struct CoopLds {
-    uint4 q[COOP_SLOTS][2][64];
+    u32x4 q[COOP_SLOTS][2][64];
     u32 t[COOP_SLOTS][64];
     u32 flag[64];
 };
+#if defined(REEF_COOP_JITTER)
+// Timing perturbation for race hunting (tools/bisect/README.md): every wave sleeps a role- and site-dependent time around
+// each barrier.  A protocol without races gives the same results with it.
+__device__ __forceinline__ void coop_jitter(int role, int site) {
+    const int k = (role * 5 + site * 3) & 7;
+    if (k == 1) __builtin_amdgcn_s_sleep(3);
+    else if (k == 2) __builtin_amdgcn_s_sleep(9);
+    else if (k == 3) __builtin_amdgcn_s_sleep(20);
+    else if (k == 4) __builtin_amdgcn_s_sleep(1);
+    else if (k == 5) __builtin_amdgcn_s_sleep(40);
+    else if (k == 6) __builtin_amdgcn_s_sleep(14);
+    else if (k == 7) __builtin_amdgcn_s_sleep(60);
+}
+#define COOP_SYNC() do { coop_jitter(threadIdx.x >> 6, __LINE__); __syncthreads(); coop_jitter(threadIdx.x >> 6, __LINE__ + 1); } while (0)
+#else
 #define COOP_SYNC() __syncthreads()
+#endif
 
-// COMPILER NOTE.  hipcc of ROCm 7.2 at -O2 and above miscompiles two of these operations inlined back to back (a
-// doubling followed by a doubling: wrong ZZ, deterministic); -opt-bisect-limit on the stand-alone reproducer
-// tools/bisect/dd.hip stops at the AMDGPU load-store-vectorizer pass, and with -mllvm -amdgpu-load-store-vectorizer=0
-// every sequence is right (tools/dbg_ops.py checks all pairs and triples).  The library is therefore built with that
-// pass off (csrc/Makefile); volatile slot accesses alone cured the reproducer but not every sequence, and cost 30 %.
+// COMPILER NOTE.  hipcc of ROCm 7.2 miscompiles sequences of these operations when values that came out of 8- or 16-byte
+// loads (ds_read_b64/b128, written as such or merged from dword loads by the SLP vectorizer or the AMDGPU load-store
+// vectorizer) are kept in registers and picked under the role branches of a later operation: in two doublings inlined back
+// to back the role that multiplies v*ZZ receives limbs 0..7 of ZZ from registers that were never loaded on its path (the
+// eight copies out of the 128-bit load results sit in another role's block; limb 8, a dword load, is copied in the right
+// place), so every wave ends with a wrong ZZ.  Deterministic, independent of timing, wrong from -O1 up (tools/bisect/:
+// self-checking reproducer, the -opt-bisect-limit history, the ISA excerpt).  Moving every such dword into a register of its
+// own with a v_mov_b32 the compiler cannot see through (coop_launder) cures every sequence at every level, with the
+// vectorizers on or off; dword loads do too, at 1 us per operation.  So: result slots and operands loaded from memory go
+// through coop_launder (coop_get_result here, load_xyzz_coop in msm_kernels.inc), and the library is also built with both
+// vectorizers off (csrc/Makefile).  tests/test_gpu_parity.py::test_group_law runs every pair and triple of operations.
 __device__ __forceinline__ void coop_put(CoopLds &L, int slot, int lane, const fe &v) {
-    L.q[slot][0][lane] = make_uint4(v.l[0], v.l[1], v.l[2], v.l[3]);
-    L.q[slot][1][lane] = make_uint4(v.l[4], v.l[5], v.l[6], v.l[7]);
+    L.q[slot][0][lane] = mk_u32x4(v.l[0], v.l[1], v.l[2], v.l[3]);
+    L.q[slot][1][lane] = mk_u32x4(v.l[4], v.l[5], v.l[6], v.l[7]);
     L.t[slot][lane] = v.l[8];
 }
+// Two readers.  coop_get is for a slot a role reads inside its own branch and consumes at once.  coop_get_result fetches
+// the result slots, whose values every wave keeps in registers and picks from under the role branches of the NEXT
+// operation: there the dwords of the 16-byte load results are first moved into registers of their own by instructions the
+// compiler cannot see through (coop_launder; see the compiler note).  REEF_COOP_WIDE_READS leaves the move out, for the
+// reproducer.
 __device__ __forceinline__ fe coop_get(const CoopLds &L, int slot, int lane) {
-    const uint4 a = L.q[slot][0][lane], b = L.q[slot][1][lane];
+    const u32x4 a = L.q[slot][0][lane], b = L.q[slot][1][lane];
     fe r;
     r.l[0] = a.x; r.l[1] = a.y; r.l[2] = a.z; r.l[3] = a.w;
     r.l[4] = b.x; r.l[5] = b.y; r.l[6] = b.z; r.l[7] = b.w;
+    r.l[8] = L.t[slot][lane];
+    return r;
+}
+__device__ __forceinline__ u32 coop_launder(u32 v) {
+#if defined(REEF_COOP_WIDE_READS)
+    return v;
+#else
+    u32 o;
+    asm("v_mov_b32 %0, %1" : "=v"(o) : "v"(v));        // not volatile: free to be scheduled, still opaque
+    return o;
+#endif
+}
+__device__ __forceinline__ fe coop_get_result(const CoopLds &L, int slot, int lane) {
+    const u32x4 a = L.q[slot][0][lane], b = L.q[slot][1][lane];
+    fe r;
+    r.l[0] = coop_launder(a.x); r.l[1] = coop_launder(a.y); r.l[2] = coop_launder(a.z); r.l[3] = coop_launder(a.w);
+    r.l[4] = coop_launder(b.x); r.l[5] = coop_launder(b.y); r.l[6] = coop_launder(b.z); r.l[7] = coop_launder(b.w);
     r.l[8] = L.t[slot][lane];
     return r;
 }
@@ -145,10 +189,10 @@ template <int C, int MODE> __device__ __forceinline__ xyzz xyzz_coop_op(const xy
     }
     COOP_SYNC();
     xyzz r;
-    r.x = coop_get(L, 7, lane);
-    r.y = coop_get(L, 8, lane);
-    r.zz = coop_get(L, 9, lane);
-    r.zzz = coop_get(L, 10, lane);
+    r.x = coop_get_result(L, 7, lane);
+    r.y = coop_get_result(L, 8, lane);
+    r.zz = coop_get_result(L, 9, lane);
+    r.zzz = coop_get_result(L, 10, lane);
     if constexpr (add) {
         const bool a_inf = xyzz_is_inf<C>(a), b_inf = xyzz_is_inf<C>(b);
         // P + P: then P = R = 0 and the formulas above give ZZ3 = 0; P + (-P) also gives ZZ3 = 0 but has R != 0.  Every wave

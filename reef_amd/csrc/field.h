@@ -35,6 +35,15 @@ namespace reef {
 typedef uint32_t u32;
 typedef uint64_t u64;
 typedef int64_t i64;
+#if defined(__HIPCC__)
+// Native vector types for the 8- and 16-byte memory accesses (global and LDS).  HIP's uint2 / uint4 are structs of scalars
+// that only become b64 / b128 instructions if a vectorizer pass merges the member accesses -- and both passes that do
+// (SLP and the AMDGPU load-store vectorizer) are switched off for this library (csrc/Makefile, tools/bisect/README.md).
+typedef u32 u32x2 __attribute__((ext_vector_type(2), may_alias));
+typedef u32 u32x4 __attribute__((ext_vector_type(4), may_alias));
+REEF_HD u32x2 mk_u32x2(u32 a, u32 b) { u32x2 v; v.x = a; v.y = b; return v; }
+REEF_HD u32x4 mk_u32x4(u32 a, u32 b, u32 c, u32 d) { u32x4 v; v.x = a; v.y = b; v.z = c; v.w = d; return v; }
+#endif
 }  // namespace reef
 
 #include "field_consts.h"

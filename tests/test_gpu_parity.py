@@ -86,7 +86,8 @@ def test_group_law(name, gpu_lib, cref):
               4: lambda p, q, k_: A(p, q), 5: lambda p, q, k_: D(p), 6: lambda p, q, k_: A(D(D(A(p, q))), p),
               11: lambda p, q, k_: D(A(p, q)), 12: lambda p, q, k_: A(A(p, q), p), 13: lambda p, q, k_: D(D(A(p, q))),
               14: lambda p, q, k_: A(D(p), q), 15: lambda p, q, k_: A(D(D(p)), q), 16: lambda p, q, k_: D(D(p)),
-              17: lambda p, q, k_: D(D(p)), 18: lambda p, q, k_: D(D(p)), 19: lambda p, q, k_: D(D(p))}
+              17: lambda p, q, k_: D(D(p)), 18: lambda p, q, k_: D(D(p)), 19: lambda p, q, k_: D(D(p)),
+              20: lambda p, q, k_: D(D(p)), 21: lambda p, q, k_: A(p, q), 22: lambda p, q, k_: C.mul(7, A(p, q))}
     for op in sorted(expect):
         assert gpu_lib.reef_test_ec_op(cid, op, P.ctypes.data, Qp.ctypes.data, k.ctypes.data, out.ctypes.data, n) == 0
         comp = cref.compress(cid, out)
@@ -580,4 +581,5 @@ def test_bench_collective_path_on_one_gpu(gpu_lib):
     line = json.loads(out.stdout.strip().splitlines()[-1])
     assert line["config"]["check"] == "dlog-ok" and line["n_gpus"] == 1
     assert line["roofline"]["achieved"] > 0 and line["roofline"]["kernel_ms"] > 0
+
 
