@@ -61,3 +61,30 @@ def test_large_document_properties(gpu_lib):
     assert tree[-1][0] == root
     q = 777
     assert M.root_from_path([int(v) for v in doc[:0]] or doc.tolist(), q, M.path_wits(doc.tolist(), tree, q), p) == root
+
+
+@pytest.mark.parametrize("rp", [0, 1, 2, 8, 9, 17, 57])
+def test_sparse_partial_rounds_equal_the_dense_definition(rp, gpu_lib):
+    """The GPU runs the partial rounds in their sparse form (constants derived on the host); the oracle applies the
+    permutation as defined.  Every count of partial rounds around the edges of the derivation: none, the dense last
+    round alone, one sparse round, the renormalisation period of 8, an odd tail."""
+    from reef_amd import merkle
+    for field, curve in ((M.Q, "pallas"), (M.P, "vesta")):
+        p = M.standin_params(field, 5, 8, rp)
+        doc = [(13 * i + 5) % 257 for i in range(21)]
+        root, tree = merkle.commit(curve, doc, p.t, p.rf, p.rp, p.rc, p.mds, p.tag_leaf, p.tag_node)
+        assert (root, tree) == M.commit(doc, p)
+
+
+def test_dense_form_kept_behind_the_switch(gpu_lib):
+    """REEF_POSEIDON_DENSE=1 (read once per process) keeps the defining dense rounds: same tree."""
+    import os
+    import subprocess
+    import sys
+    code = ("import sys; sys.path.insert(0, '.');\n"
+            "from oracle import merkle_oracle as M\nfrom reef_amd import merkle\n"
+            "p = M.standin_params(); doc = list(range(2, 40))\n"
+            "assert merkle.commit('pallas', doc, p.t, p.rf, p.rp, p.rc, p.mds, p.tag_leaf, p.tag_node) == M.commit(doc, p)\nprint('dense-ok')\n")
+    out = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, REEF_POSEIDON_DENSE="1"), capture_output=True, text=True, timeout=300,
+                         cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    assert "dense-ok" in out.stdout, out.stderr[-2000:]
