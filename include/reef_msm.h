@@ -144,6 +144,18 @@ reef_status reef_ipa_cross_terms(reef_msm_ctx *ctx, const reef_fe *a, size_t n_k
                                  const reef_fe *w1s, const reef_fe *w2s, size_t k, reef_jacobian *out_l,
                                  reef_jacobian *out_r);
 
+/* A commitment over FOLDED generators without folding them: what CE::commit(&gens.fold(..).fold(..), v) [R] returns when
+ * `gens` is the resident key of ctx.  With n_k = n / 2^k generators after k folds (challenges w1s[m], w2s[m], canonical
+ * integers on the host, same convention as reef_fold),
+ *     out = sum_{j < len} v[j] * G^(k)_{off + j},     off + len <= n_k,
+ * computed as one MSM over the original key with scalars v[j] * prod(challenges).  `off`/`len` select a slice, so the halves
+ * of CommitmentGens::split_at and the last remaining generator (len = 1 after log2(n) folds, v = [1]) are the same call:
+ * a CommitmentGens that records its folds instead of performing them (reef_amd/provider.py FoldedGens,
+ * host/reef_provider.hpp) serves nova-snark's ipa_pc unchanged -- no 255-bit scalar multiplication per generator, no
+ * re-keying.  k = 0 is a commitment over a slice of the key.  The key length must be a multiple of 2^k. */
+reef_status reef_msm_folded(reef_msm_ctx *ctx, const reef_fe *v, size_t len, size_t off, int v_loc, bool is_mont,
+                            const reef_fe *w1s, const reef_fe *w2s, size_t k, reef_jacobian *out, int out_loc);
+
 /* ---------------------------------------------------------------------------------------------
  * (3) Stateless helpers around the MSMs.
  * ------------------------------------------------------------------------------------------- */

@@ -89,6 +89,7 @@ def load() -> ctypes.CDLL:
         "reef_msm_ctx_plan": (c_int, [vp, POINTER(c_uint32), POINTER(c_uint32), POINTER(c_uint32), POINTER(c_uint32)]),
         "reef_msm_plan_for": (c_int, [c_size_t, c_uint32, c_uint32, POINTER(c_uint32), POINTER(c_uint32), POINTER(c_uint32),
                                       POINTER(c_uint32)]),
+        "reef_msm_folded": (c_int, [vp, vp, c_size_t, c_size_t, c_int, c_bool, vp, vp, c_size_t, vp, c_int]),
         "reef_sc_create": (c_int, [POINTER(vp), c_int, c_size_t]),
         "reef_sc_destroy": (None, [vp]),
         "reef_sc_set_table": (c_int, [vp, c_int, vp, c_size_t, c_int]),

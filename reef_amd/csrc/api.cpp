@@ -184,6 +184,12 @@ reef_status reef_ipa_cross_terms(reef_msm_ctx *ctx, const reef_fe *a, size_t n_k
     return vt(ctx->curve)->ipa_cross(ctx->impl, a, n_k, a_loc, is_mont, w1s, w2s, k, out_l, out_r);
 }
 
+reef_status reef_msm_folded(reef_msm_ctx *ctx, const reef_fe *v, size_t len, size_t off, int v_loc, bool is_mont, const reef_fe *w1s,
+                            const reef_fe *w2s, size_t k, reef_jacobian *out, int out_loc) {
+    if (!ctx) { set_error("null argument"); return REEF_ERR_ARG; }
+    return vt(ctx->curve)->msm_folded(ctx->impl, v, len, off, v_loc, is_mont, w1s, w2s, k, out, out_loc);
+}
+
 #define STATELESS_PROLOGUE(curve)          \
     const CurveVTable *v = vt(curve);      \
     if (!v) return REEF_ERR_ARG;           \

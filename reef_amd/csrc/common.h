@@ -66,6 +66,8 @@ struct CurveVTable {
                                     const reef_fe *blinds, const reef_affine *h, bool blinds_are_mont, reef_jacobian *out, int out_loc);
     reef_status (*ipa_cross)(void *impl, const reef_fe *a, size_t n_k, int loc, bool is_mont, const reef_fe *w1s, const reef_fe *w2s, size_t k,
                              reef_jacobian *out_l, reef_jacobian *out_r);
+    reef_status (*msm_folded)(void *impl, const reef_fe *v, size_t len, size_t off, int loc, bool is_mont, const reef_fe *w1s, const reef_fe *w2s,
+                              size_t k, reef_jacobian *out, int out_loc);
     reef_status (*fold)(const reef_affine *gens, size_t half, int loc, const reef_fe *w1, const reef_fe *w2, reef_affine *out);
     reef_status (*normalize)(const reef_jacobian *in, size_t n, int loc, reef_affine *out_aff, uint8_t *out_comp);
     reef_status (*sum_points)(const reef_jacobian *in, size_t n, int loc, reef_jacobian *out);

@@ -5,6 +5,7 @@
 //   CommitmentGens<CURVE>::commit(v, blind)       CE::commit(&gens, &v, &blind)          src/backend/commitment.rs:349-351,360-361,422,430
 //   CommitmentGens<CURVE>::fold(w1, w2)           CommitmentGens::fold (ipa_pc)          reached from src/backend/framework.rs:695
 //   CommitmentGens<CURVE>::ipa_cross_terms(..)    the two cross-term commitments of an IPA round, without folding the generators
+//   CommitmentGens<CURVE>::commit_folded(..)      any commitment over folded generators (a slice of them), folds recorded not performed
 //   HyraxPC<CURVE>::commit / commit_symbols       HyraxPC::commit(&poly)                 src/backend/commitment.rs:187
 //   HyraxPC<CURVE>::bind_rows                     first step of HyraxPC::prove_eval      src/backend/commitment.rs:371-391 (and :357)
 //   SumCheck                                      gen_eq_table / linear_mle_product      src/backend/r1cs_helper.rs:441-544, driven as in r1cs.rs:2318-2385
@@ -80,6 +81,15 @@ template <int CURVE> class CommitmentGens {
     }
 
     // Cross terms (L, R) of IPA round k = w1s.size() over THESE generators (no fold): a = a_lo || a_hi.
+    // CE::commit over the generators w1s.size() folds away from this key, slice [off, off + len), without folding them
+    // (reef_msm_folded): what a CommitmentGens that records its folds returns from commit / split_at().commit
+    reef_jacobian commit_folded(const reef_fe *v, size_t len, size_t off, const std::vector<reef_fe> &w1s, const std::vector<reef_fe> &w2s,
+                                int v_loc = REEF_HOST) const {
+        if (w1s.size() != w2s.size()) throw std::invalid_argument("challenge vectors differ in length");
+        reef_jacobian out;
+        check(reef_msm_folded(ctx_, v, len, off, v_loc, true, w1s.data(), w2s.data(), w1s.size(), &out, REEF_HOST), "reef_msm_folded");
+        return out;
+    }
     std::pair<reef_jacobian, reef_jacobian> ipa_cross_terms(const reef_fe *a, size_t n_k, const std::vector<reef_fe> &w1s,
                                                             const std::vector<reef_fe> &w2s, int a_loc = REEF_HOST) const {
         if (w1s.size() != w2s.size()) throw std::logic_error("one (w1, w2) pair per round");

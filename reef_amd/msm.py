@@ -226,6 +226,19 @@ class MsmContext:
                                              w2.ctypes.data, k, out_l.ctypes.data, out_r.ctypes.data))
         return out_l, out_r
 
+    def msm_folded(self, v: np.ndarray, w1s, w2s, off: int = 0, *, is_mont: bool = True) -> np.ndarray:
+        """Commitment over the generators len(w1s) folds away from this key, slice [off, off + len(v)), without folding
+        them (reef_msm_folded): v (len, 4) uint64 scalars, challenges as ints."""
+        v = np.ascontiguousarray(v, dtype=np.uint64).reshape(-1, 4)
+        k = len(w1s)
+        assert len(w2s) == k
+        w1 = np.array([list(scalar_to_limbs(w)) for w in w1s], dtype=np.uint64).reshape(k, 4) if k else np.zeros((1, 4), np.uint64)
+        w2 = np.array([list(scalar_to_limbs(w)) for w in w2s], dtype=np.uint64).reshape(k, 4) if k else np.zeros((1, 4), np.uint64)
+        out = np.zeros(12, dtype=np.uint64)
+        check(self._lib.reef_msm_folded(self._h, v.ctypes.data, v.shape[0], off, REEF_HOST, bool(is_mont), w1.ctypes.data, w2.ctypes.data, k,
+                                        out.ctypes.data, REEF_HOST))
+        return out
+
     def msm_rows(self, scalars: Buf, rows: int, row_len: int, *, is_mont: bool = True, max_scalar_bits: int = 0,
                  blinds: Optional[Buf] = None, h: Optional[Buf] = None, out: Optional[Buf] = None) -> Buf:
         if row_len > self.n:

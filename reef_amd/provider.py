@@ -13,8 +13,8 @@ reference's call sites and so that a maintainer can see what each Rust method ma
                                                                from_label is row N1 of SURVEY 8f)
     CE::commit(&gens, &v, &blind)                      [R]    CommitmentGens.commit(v, blind)
         (commitment.rs:350,361,422,430)
-    gens.fold(w1, w2) / split_at / combine             [R]    CommitmentGens.fold / split_at / combine
-        (ipa_pc inside CompressedSNARK::prove, framework.rs:695)
+    gens.fold(w1, w2) / split_at / combine             [R]    CommitmentGens.fold / split_at / combine  (the points), or
+        (ipa_pc inside CompressedSNARK::prove, framework.rs:695)      CommitmentGens.fold_lazy -> FoldedGens (fold recorded, never performed)
     HyraxPC::commit(&poly)                             [R]    HyraxPC.commit(poly)
         (commitment.rs:187)
     Commitment::compress()                             [R]    Commitment.compress()
@@ -126,6 +126,10 @@ class CommitmentGens:
         folded = msm.fold(self.curve, self.bases, n // 2, w1, w2)
         return CommitmentGens(self.curve, folded, self.h, precompute=False)
 
+    # the same without the scalar multiplications: the fold is recorded, commitments go over this (resident) key
+    def fold_lazy(self, w1: int, w2: int) -> "FoldedGens":
+        return FoldedGens(self).fold(w1, w2)
+
     def split_at(self, k: int) -> Tuple["CommitmentGens", "CommitmentGens"]:
         return (CommitmentGens(self.curve, self.bases[:k].copy(), self.h, precompute=False),
                 CommitmentGens(self.curve, self.bases[k:].copy(), self.h, precompute=False))
@@ -133,6 +137,56 @@ class CommitmentGens:
     def combine(self, other: "CommitmentGens") -> "CommitmentGens":
         assert self.curve == other.curve
         return CommitmentGens(self.curve, np.concatenate([self.bases, other.bases]), self.h, precompute=False)
+
+
+class FoldedGens:
+    """`gens.fold(w1, w2)` that records the fold instead of performing it: the generators after k folds are fixed linear
+    combinations of the resident key, so every commitment over them -- the cross terms of an IPA round over the halves of
+    `split_at`, the last remaining generator -- is one MSM over the ORIGINAL pre-shifted key (reef_msm_folded).  Same
+    methods as CommitmentGens where nova-snark's ipa_pc [R] uses them; `materialize()` performs the folds (K3) when the
+    points themselves are wanted."""
+
+    def __init__(self, root: "CommitmentGens", w1s=(), w2s=(), off: int = 0, length: Optional[int] = None):
+        self.root, self.w1s, self.w2s, self.off = root, list(w1s), list(w2s), off
+        n_k = len(root) >> len(self.w1s)
+        if (n_k << len(self.w1s)) != len(root):
+            raise ValueError("the key length must be a multiple of 2^folds")
+        self.length = n_k - off if length is None else length
+        if off < 0 or self.length < 0 or off + self.length > n_k:
+            raise ValueError("slice outside the folded generators")
+        self.curve, self.h = root.curve, root.h
+
+    def __len__(self) -> int:
+        return self.length
+
+    def commit(self, v: np.ndarray, blind: Optional[np.ndarray] = None, *, is_mont: bool = True) -> Commitment:
+        v = np.ascontiguousarray(v, dtype=np.uint64).reshape(-1, 4)
+        if v.shape[0] > self.length:
+            raise ValueError(f"vector of {v.shape[0]} scalars exceeds {self.length} generators")
+        c = Commitment(self.curve, self.root._context().msm_folded(v, self.w1s, self.w2s, self.off, is_mont=is_mont))
+        if blind is None:
+            return c
+        if self.h is None:
+            raise ValueError("these generators have no blinding generator")
+        hg = CommitmentGens(self.curve, self.h.reshape(1, 8))
+        try:
+            return c + hg.commit(np.ascontiguousarray(blind, dtype=np.uint64).reshape(1, 4), is_mont=is_mont)
+        finally:
+            hg.close()
+
+    def fold(self, w1: int, w2: int) -> "FoldedGens":
+        if self.off or self.length != len(self.root) >> len(self.w1s) or self.length % 2:
+            raise ValueError("fold needs the whole, even-sized set of folded generators")
+        return FoldedGens(self.root, self.w1s + [w1], self.w2s + [w2])
+
+    def split_at(self, k: int) -> Tuple["FoldedGens", "FoldedGens"]:
+        return FoldedGens(self.root, self.w1s, self.w2s, self.off, k), FoldedGens(self.root, self.w1s, self.w2s, self.off + k, self.length - k)
+
+    def materialize(self) -> "CommitmentGens":
+        bases = self.root.bases
+        for w1, w2 in zip(self.w1s, self.w2s):
+            bases = msm.fold(self.curve, bases, bases.shape[0] // 2, w1, w2)
+        return CommitmentGens(self.curve, bases[self.off:self.off + self.length].copy(), self.h, precompute=False)
 
 
 class HyraxPC:

@@ -243,3 +243,48 @@ def test_cpp_provider_mirror_matches_oracle(gpu_lib, cref):
     assert got["sumcheck_final"] == t[0].to_bytes(32, "little").hex()
     assert got["error_throws"] is True
 
+
+
+@pytest.mark.parametrize("groups", [1, 0])
+def test_lazy_fold_serves_the_whole_ipa(groups, gpu_lib, cref):
+    """nova's ipa_pc as it is written -- split_at, two commits, fold, ... down to one generator -- on generators that RECORD
+    their folds (FoldedGens over the resident key, reef_msm_folded): every L, R and the last generator equal what the
+    oracle gets by folding the generators for real."""
+    from reef_amd import provider as P
+    cid, name = 0, "pallas"
+    C = CURVES[name]
+    n = 128
+    root = P.CommitmentGens(name, cref.gen_bases_ap(cid, 33, 7, n), precompute=bool(groups))
+    rng = SplitMix64(4242)
+    lazy = P.FoldedGens(root)
+    gens = root.bases                                           # the oracle's generators, folded for real every round
+    a = cref.gen_scalars(cid, 9, n, mont=False)
+    for k in range(7):
+        n_k = n >> k
+        half = n_k // 2
+        assert len(lazy) == n_k
+        g_lo, g_hi = lazy.split_at(half)
+        L = g_hi.commit(a[:half].copy(), is_mont=False)
+        R = g_lo.commit(a[half:n_k].copy(), is_mont=False)
+        assert L.compress() == cref.compress(cid, cref.msm_pippenger(cid, np.ascontiguousarray(gens[half:n_k]), a[:half].copy(), mont=False)), k
+        assert R.compress() == cref.compress(cid, cref.msm_pippenger(cid, np.ascontiguousarray(gens[:half]), a[half:n_k].copy(), mont=False)), k
+        if k == 2:                                              # a ragged slice and the recorded folds performed for real
+            assert (lazy.materialize().bases == gens[:n_k]).all()
+            mid = FoldedGensSlice = P.FoldedGens(root, lazy.w1s, lazy.w2s, 3, 5)
+            assert mid.commit(a[:5].copy(), is_mont=False).compress() == cref.compress(
+                cid, cref.msm_pippenger(cid, np.ascontiguousarray(gens[3:8]), a[:5].copy(), mont=False))
+        w1, w2 = uniform_scalar(rng, C.order), uniform_scalar(rng, C.order)
+        lazy = lazy.fold(w1, w2)
+        gens = cref.fold(cid, np.ascontiguousarray(gens[:n_k]), w1, w2)
+        alo = [cref.limbs_to_int(x) for x in a[:half]]
+        ahi = [cref.limbs_to_int(x) for x in a[half:n_k]]
+        a = P.scalars_to_array([(w2 * x + w1 * y) % C.order for x, y in zip(alo, ahi)], name)   # any fold of a: only shapes matter here
+    assert len(lazy) == 1
+    one = P.scalars_to_array([1], name)
+    last = lazy.commit(one, is_mont=False)                      # the last remaining generator, as a point
+    assert last.to_affine().tobytes() == np.ascontiguousarray(gens[0]).tobytes()
+    with pytest.raises(ValueError):
+        lazy.fold(1, 2)
+    with pytest.raises(ValueError):
+        P.FoldedGens(root, [1], [2], 60, 10)
+    root.close()
