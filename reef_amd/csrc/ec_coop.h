@@ -61,9 +61,10 @@ __device__ __forceinline__ void coop_jitter(int role, int site) {
 // place), so every wave ends with a wrong ZZ.  Deterministic, independent of timing, wrong from -O1 up (tools/bisect/:
 // self-checking reproducer, the -opt-bisect-limit history, the ISA excerpt).  Moving every such dword into a register of its
 // own with a v_mov_b32 the compiler cannot see through (coop_launder) cures every sequence at every level, with the
-// vectorizers on or off; dword loads do too, at 1 us per operation.  So: result slots and operands loaded from memory go
-// through coop_launder (coop_get_result here, load_xyzz_coop in msm_kernels.inc), and the library is also built with both
-// vectorizers off (csrc/Makefile).  tests/test_gpu_parity.py::test_group_law runs every pair and triple of operations.
+// vectorizers on or off; dword loads do too.  The library does both: it is built with both vectorizers off and writes its
+// wide accesses as HIP's uint4 structs (field.h), so every access is a dword instruction, and result slots and operands
+// loaded from memory still go through coop_launder (coop_get_result here, load_xyzz_coop in msm_kernels.inc; 1-3 %) in case
+// a build turns the passes back on.  tests/test_gpu_parity.py::test_group_law runs every pair and triple of operations.
 __device__ __forceinline__ void coop_put(CoopLds &L, int slot, int lane, const fe &v) {
     L.q[slot][0][lane] = mk_u32x4(v.l[0], v.l[1], v.l[2], v.l[3]);
     L.q[slot][1][lane] = mk_u32x4(v.l[4], v.l[5], v.l[6], v.l[7]);

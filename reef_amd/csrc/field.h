@@ -36,13 +36,23 @@ typedef uint32_t u32;
 typedef uint64_t u64;
 typedef int64_t i64;
 #if defined(__HIPCC__)
-// Native vector types for the 8- and 16-byte memory accesses (global and LDS).  HIP's uint2 / uint4 are structs of scalars
-// that only become b64 / b128 instructions if a vectorizer pass merges the member accesses -- and both passes that do
-// (SLP and the AMDGPU load-store vectorizer) are switched off for this library (csrc/Makefile, tools/bisect/README.md).
+// 8- and 16-byte memory accesses are written with HIP's uint2 / uint4 -- structs of scalars -- and the library is built with
+// both vectorizer passes off (csrc/Makefile), so they stay dword instructions.  Measured on MI355X that is FASTER than native
+// vector types (ext_vector_type: ds/global b128 instructions) wherever it matters here -- the latency-bound tail kernels
+// lose 5-15 % to the register tuples of wide accesses, the bandwidth-bound kernels do not care (profiles/r02_vector_types_ab.txt)
+// -- and it keeps hipcc's miscompile of wide load results (ec_coop.h, compiler note) out of reach.  REEF_VEC_VARIANT=2
+// selects the native vectors for that comparison.
+#if defined(REEF_VEC_VARIANT) && REEF_VEC_VARIANT == 2
 typedef u32 u32x2 __attribute__((ext_vector_type(2), may_alias));
 typedef u32 u32x4 __attribute__((ext_vector_type(4), may_alias));
 REEF_HD u32x2 mk_u32x2(u32 a, u32 b) { u32x2 v; v.x = a; v.y = b; return v; }
 REEF_HD u32x4 mk_u32x4(u32 a, u32 b, u32 c, u32 d) { u32x4 v; v.x = a; v.y = b; v.z = c; v.w = d; return v; }
+#else
+typedef uint2 u32x2;
+typedef uint4 u32x4;
+REEF_HD u32x2 mk_u32x2(u32 a, u32 b) { return make_uint2(a, b); }
+REEF_HD u32x4 mk_u32x4(u32 a, u32 b, u32 c, u32 d) { return make_uint4(a, b, c, d); }
+#endif
 #endif
 }  // namespace reef
 

@@ -29,3 +29,6 @@ PY
 python $root/tools/time_rows.py 1024 2048 131 > $out/${R}_rows_timing.txt 2>&1; python $root/tools/time_rows.py 4096 8192 7 >> $out/${R}_rows_timing.txt 2>&1
 python $root/tools/time_sumcheck.py 21 26 > $out/${R}_sumcheck_timing.txt 2>&1
 python $root/tools/time_mle.py > $out/${R}_mle_timing.txt 2>&1
+(python $root/tools/time_merkle.py; echo "# REEF_POSEIDON_DENSE=1 (partial rounds in the defining dense form), same box:"; REEF_POSEIDON_DENSE=1 python $root/tools/time_merkle.py | grep symbols) > $out/${R}_merkle_timing.txt 2>&1
+python $root/tools/time_keygen.py $out/${R}_keygen_timing.json > /dev/null 2>&1
+python $root/tools/time_setup.py $out/${R}_setup_timing.json > /dev/null 2>&1
