@@ -3,6 +3,8 @@
 #include <stdarg.h>
 #include <stdio.h>
 #include <vector>
+#include <new>
+#include <exception>
 #include <stdlib.h>
 #include <string.h>
 
@@ -65,6 +67,19 @@ struct reef_msm_ctx {
     int curve;
     void *impl;
 };
+
+// No C++ exception crosses the C ABI: host allocations sized by the caller (key-derivation stream, staging vectors) can fail.
+template <class F> static reef_status guarded(F &&f) {
+    try {
+        return f();
+    } catch (const std::bad_alloc &) {
+        set_error("host memory exhausted");
+        return REEF_ERR_OOM;
+    } catch (const std::exception &e) {
+        set_error("internal error: %s", e.what());
+        return REEF_ERR_HIP;
+    }
+}
 
 extern "C" {
 
@@ -160,12 +175,12 @@ reef_status reef_msm_ctx_plan(reef_msm_ctx *ctx, uint32_t *c, uint32_t *windows,
 reef_status reef_msm(reef_msm_ctx *ctx, const reef_fe *scalars, size_t n, int scalars_loc, bool is_mont, reef_jacobian *out,
                      int out_loc) {
     if (!ctx) { set_error("null argument"); return REEF_ERR_ARG; }
-    return vt(ctx->curve)->msm(ctx->impl, scalars, n, scalars_loc, is_mont, out, out_loc);
+    return guarded([&] { return vt(ctx->curve)->msm(ctx->impl, scalars, n, scalars_loc, is_mont, out, out_loc); });
 }
 reef_status reef_msm_rows(reef_msm_ctx *ctx, const reef_fe *scalars, size_t rows, size_t row_len, int scalars_loc, bool is_mont,
                           uint32_t max_scalar_bits, const reef_fe *blinds, const reef_affine *h, reef_jacobian *out, int out_loc) {
     if (!ctx) { set_error("null argument"); return REEF_ERR_ARG; }
-    return vt(ctx->curve)->msm_rows(ctx->impl, scalars, rows, row_len, scalars_loc, is_mont, max_scalar_bits, blinds, h, out, out_loc);
+    return guarded([&] { return vt(ctx->curve)->msm_rows(ctx->impl, scalars, rows, row_len, scalars_loc, is_mont, max_scalar_bits, blinds, h, out, out_loc); });
 }
 
 reef_status reef_msm_plan_for(size_t n, uint32_t window_bits, uint32_t bucket_groups, uint32_t *c, uint32_t *windows,
@@ -176,18 +191,18 @@ reef_status reef_msm_plan_for(size_t n, uint32_t window_bits, uint32_t bucket_gr
 reef_status reef_msm_rows_symbols(reef_msm_ctx *ctx, const uint8_t *symbols, size_t rows, size_t row_len, int loc, uint32_t symbol_bits,
                                   const reef_fe *blinds, const reef_affine *h, bool blinds_are_mont, reef_jacobian *out, int out_loc) {
     if (!ctx) { set_error("null argument"); return REEF_ERR_ARG; }
-    return vt(ctx->curve)->msm_rows_symbols(ctx->impl, symbols, rows, row_len, loc, symbol_bits, blinds, h, blinds_are_mont, out, out_loc);
+    return guarded([&] { return vt(ctx->curve)->msm_rows_symbols(ctx->impl, symbols, rows, row_len, loc, symbol_bits, blinds, h, blinds_are_mont, out, out_loc); });
 }
 reef_status reef_ipa_cross_terms(reef_msm_ctx *ctx, const reef_fe *a, size_t n_k, int a_loc, bool is_mont, const reef_fe *w1s,
                                  const reef_fe *w2s, size_t k, reef_jacobian *out_l, reef_jacobian *out_r) {
     if (!ctx) { set_error("null argument"); return REEF_ERR_ARG; }
-    return vt(ctx->curve)->ipa_cross(ctx->impl, a, n_k, a_loc, is_mont, w1s, w2s, k, out_l, out_r);
+    return guarded([&] { return vt(ctx->curve)->ipa_cross(ctx->impl, a, n_k, a_loc, is_mont, w1s, w2s, k, out_l, out_r); });
 }
 
 reef_status reef_msm_folded(reef_msm_ctx *ctx, const reef_fe *v, size_t len, size_t off, int v_loc, bool is_mont, const reef_fe *w1s,
                             const reef_fe *w2s, size_t k, reef_jacobian *out, int out_loc) {
     if (!ctx) { set_error("null argument"); return REEF_ERR_ARG; }
-    return vt(ctx->curve)->msm_folded(ctx->impl, v, len, off, v_loc, is_mont, w1s, w2s, k, out, out_loc);
+    return guarded([&] { return vt(ctx->curve)->msm_folded(ctx->impl, v, len, off, v_loc, is_mont, w1s, w2s, k, out, out_loc); });
 }
 
 #define STATELESS_PROLOGUE(curve)          \
@@ -303,7 +318,7 @@ reef_status reef_merkle_commit(int curve, const reef_poseidon_params *params, co
     const CurveVTable *v = vt(curve);
     if (!v) return REEF_ERR_ARG;
     REEF_TRY(require_gpu());
-    return v->merkle_commit(params, doc, n, doc_loc, is_mont, tree_out, tree_loc, root_out);
+    return guarded([&] { return v->merkle_commit(params, doc, n, doc_loc, is_mont, tree_out, tree_loc, root_out); });
 }
 
 reef_status reef_derive_generators(int curve, const uint8_t *label, size_t label_len, size_t n, const reef_keygen_params *params, bool is_mont,
@@ -311,7 +326,7 @@ reef_status reef_derive_generators(int curve, const uint8_t *label, size_t label
     const CurveVTable *v = vt(curve);
     if (!v) return REEF_ERR_ARG;
     REEF_TRY(require_gpu());
-    return v->derive_generators(label, label_len, n, params, is_mont, out, out_loc);
+    return guarded([&] { return v->derive_generators(label, label_len, n, params, is_mont, out, out_loc); });
 }
 void reef_shake256(const uint8_t *in, size_t in_len, uint8_t *out, size_t out_len) { reef::shake256(in, in_len, out, out_len); }
 

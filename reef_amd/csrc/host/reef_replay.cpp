@@ -31,6 +31,7 @@
 #include <vector>
 
 #include "reef_msm.h"
+#include "replay_standins.h"
 
 #define CK(x)                                                                              \
     do {                                                                                   \
@@ -99,13 +100,14 @@ struct Shape {
     int symbol_bits;         // width of a document symbol (alphabet + EOF/EPSILON, framework.rs:978-1011)
     int table_log;           // log2 of the table the per-step nlookup sum-check runs over (r1cs.rs:2318-2385); 0: not replayed
     int lookups;             // lookups folded per step (batch size)
+    int merkle_log;          // --merkle: log2 of the document the Poseidon tree commits to (0: Hyrax commitment)
 };
 // BASELINE.json configs as sized in SURVEY.md 8 (predictions of costs.rs, not measurements)
 static const Shape SHAPES[] = {
-    {"cfg1_9B_ascii", 17000, 16700, 11400, 11376, 3, 4, 4, 8, 10, 4},
-    {"cfg3_1MiB_ascii_password", 26000, 26000, 11400, 11376, 3, 2048, 21, 8, 21, 16},
-    {"cfg4_16MiB_dna_hybrid_b32", 39000, 39000, 11400, 11376, 4, 8192, 25, 3, 26, 32},
-    {"cfg5_64MiB_utf8_merkle", 65000, 65000, 11400, 11376, 4, 0, 0, 8, 0, 32},
+    {"cfg1_9B_ascii", 17000, 16700, 11400, 11376, 3, 4, 4, 8, 10, 4, 0},
+    {"cfg3_1MiB_ascii_password", 26000, 26000, 11400, 11376, 3, 2048, 21, 8, 21, 16, 0},
+    {"cfg4_16MiB_dna_hybrid_b32", 39000, 39000, 11400, 11376, 4, 8192, 25, 3, 26, 32, 0},
+    {"cfg5_64MiB_utf8_merkle", 65000, 65000, 11400, 11376, 4, 0, 0, 8, 0, 32, 26},
 };
 
 struct Curve {
@@ -430,6 +432,38 @@ int main(int argc, char **argv) {
         reef_sc_destroy(sc);
     }
 
+    // ---- rows N1 and N4 with STAND-IN parameters (replay_standins.h): the keys derived from a label on the GPU, and for
+    // --merkle the Poseidon tree of the document.  Timing only: parity is tests/test_gpu_keygen.py / test_gpu_merkle.py.
+    double derive_ms = 0, merkle_ms = 0;
+    for (Curve &c : cv) {
+        reef_keygen_params kp;
+        const reef_fe *sp = c.id == REEF_PALLAS ? STANDIN_KEYGEN_0 : STANDIN_KEYGEN_1;
+        const char *dst = c.id == REEF_PALLAS ? STANDIN_KEYGEN_DST_0 : STANDIN_KEYGEN_DST_1;
+        kp.a = sp[0]; kp.b = sp[1]; kp.z = sp[2];
+        memcpy(kp.iso, sp + 3, 13 * sizeof(reef_fe));
+        kp.dst = (const uint8_t *)dst; kp.dst_len = (uint32_t)strlen(dst); kp.little_endian = 0;
+        reef_affine *d_key = (reef_affine *)reef_device_alloc(c.n * sizeof(reef_affine));
+        CK(reef_derive_generators(c.id, (const uint8_t *)"ck", 2, c.n, &kp, false, d_key, REEF_DEVICE));   // warm-up
+        auto t0 = clk::now();
+        CK(reef_derive_generators(c.id, (const uint8_t *)"ck", 2, c.n, &kp, false, d_key, REEF_DEVICE));
+        derive_ms += ms_since(t0);
+        reef_device_free(d_key);
+    }
+    if (sh->merkle_log) {
+        const size_t n_doc = (size_t)1 << sh->merkle_log;
+        std::vector<uint32_t> doc(n_doc);
+        for (size_t i = 0; i < n_doc; ++i) doc[i] = (uint32_t)((i * 2654435761u) >> 24);               // one-byte symbols
+        reef_poseidon_params pp;
+        pp.width = 5; pp.full_rounds = STANDIN_POSEIDON_RF; pp.partial_rounds = STANDIN_POSEIDON_RP; pp.reserved = 0;
+        pp.round_constants = STANDIN_POSEIDON_RC; pp.mds = STANDIN_POSEIDON_MDS;
+        pp.tag_leaf = STANDIN_POSEIDON_TAGS[0]; pp.tag_node = STANDIN_POSEIDON_TAGS[1];
+        reef_fe root;
+        CK(reef_merkle_commit(REEF_PALLAS, &pp, doc.data(), (size_t)1 << 16, REEF_HOST, false, nullptr, REEF_HOST, &root));   // warm-up
+        auto t0 = clk::now();
+        CK(reef_merkle_commit(REEF_PALLAS, &pp, doc.data(), n_doc, REEF_HOST, false, nullptr, REEF_HOST, &root));
+        merkle_ms = ms_since(t0);
+    }
+
     const size_t pairs_step = sh->c2 + sh->w1 + sh->c1 + sh->w2;
     printf("{\"replay\": \"%s\", \"ipa\": \"%s\", \"note\": \"MSM work of reef --prove replayed through the C ABI; host-side proving work not included\", "
            "\"shapes\": \"PREDICTED by Reef's cost model (src/backend/costs.rs as restated in SURVEY.md 8), not measured on a Reef run\", "
@@ -438,10 +472,11 @@ int main(int argc, char **argv) {
            "\"ms_per_step_batched_pairs\": %.3f, \"pairs_per_step\": %zu, \"final_snark_ms\": %.3f, \"ipa_pallas_ms\": %.3f, \"ipa_pallas_rounds\": %d, \"ipa_vesta_ms\": %.3f, "
            "\"ipa_vesta_rounds\": %d, \"consistency_ipa_ms\": %.3f, \"consistency_rounds\": %d, \"total_prove_msm_ms\": %.3f, "
            "\"commit_hyrax_ms\": %.3f, \"commit_hyrax_first_call_ms\": %.3f, \"sumcheck_table_log\": %d, \"sumcheck_ms_per_step\": %.3f, "
-           "\"doc_poly_bind_rows_ms\": %.3f, \"total_prove_gpu_ms\": %.3f}\n",
+           "\"doc_poly_bind_rows_ms\": %.3f, \"total_prove_gpu_ms\": %.3f, \"derive_both_keys_ms\": %.3f, \"commit_merkle_log\": %d, \"commit_merkle_ms\": %.3f, "
+           "\"standins\": \"key derivation and Poseidon run on stand-in parameter sets (replay_standins.h), timing only\"}\n",
            sh->name, nofold ? "cross terms over the original key (no generator fold)" : "generator fold per round", g_checked, cv[0].n, cv[1].n, sh->steps, setup_ms, steps_ms, steps_ms / sh->steps, steps_batched_ms / sh->steps, pairs_step, final_ms, ipa1_ms, r1, ipa2_ms, r2,
            cons_ms, r3, steps_ms + final_ms + cons_ms, commit_ms, commit_first_ms, sh->table_log, sc_step_ms, mle_ms,
-           steps_ms + final_ms + cons_ms + sh->steps * sc_step_ms + mle_ms);
+           steps_ms + final_ms + cons_ms + sh->steps * sc_step_ms + mle_ms, derive_ms, sh->merkle_log, merkle_ms);
     for (Curve &c : cv) {
         reef_msm_ctx_destroy(c.key);
         reef_msm_ctx_destroy(c.one);
