@@ -37,8 +37,8 @@ FMUL_PEAK = 1.57e11            # Montgomery products/s chip-wide, measured (reef
 def parse():
     p = argparse.ArgumentParser()
     p.add_argument("--gpus", type=int, default=1)
-    p.add_argument("--steps", type=int, default=20)
-    p.add_argument("--warmup", type=int, default=3)
+    p.add_argument("--steps", type=int, default=100, help="timed steps (100 x 1.35 ms: long enough for an external sampler to see the GPU busy)")
+    p.add_argument("--warmup", type=int, default=5)
     p.add_argument("--logn", type=int, default=20, help="log2 of points per GPU (BASELINE configs[1]: 20)")
     p.add_argument("--curve", default="pallas")
     p.add_argument("--scalars", default="uniform", choices=["uniform", "witness"])
