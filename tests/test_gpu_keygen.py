@@ -60,3 +60,15 @@ def test_key_sized_derivation_properties(gpu_lib):
     X, Y, Z = (sum(int(got[4 * c + j]) << (64 * j) for j in range(4)) * rinv % p for c in range(3))
     zi = pow(Z, -1, p)
     assert (X * zi * zi % p, Y * zi * zi * zi % p) == acc
+
+
+def test_gpu_matches_committed_fixture(gpu_lib):
+    import json
+    import os
+    from reef_amd import keygen
+    data = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "next_rows_golden.json")))
+    for case in data["keygen"]:
+        k = K.standin_params(case["curve"], case["root_index"], case["little_endian"])
+        raw = keygen.derive_generators(case["curve"], bytes.fromhex(case["label_hex"]), len(case["points"]), k.a, k.b, k.z, k.iso, k.dst, k.little_endian)
+        got = keygen.points_to_ints(case["curve"], raw)
+        assert [[hex(p[0]), hex(p[1])] for p in got] == case["points"]

@@ -88,3 +88,14 @@ def test_dense_form_kept_behind_the_switch(gpu_lib):
     out = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, REEF_POSEIDON_DENSE="1"), capture_output=True, text=True, timeout=300,
                          cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     assert "dense-ok" in out.stdout, out.stderr[-2000:]
+
+
+def test_gpu_matches_committed_fixture(gpu_lib):
+    import json
+    import os
+    from reef_amd import merkle
+    data = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "next_rows_golden.json")))
+    for case in data["merkle"]:
+        p = M.standin_params(M.Q if case["scalar_field_of"] == "pallas" else M.P, 5, case["rf"], case["rp"])
+        root, tree = merkle.commit(case["scalar_field_of"], case["doc"], p.t, p.rf, p.rp, p.rc, p.mds, p.tag_leaf, p.tag_node)
+        assert hex(root) == case["root"] and [len(l) for l in tree] == case["level_sizes"] and hex(tree[0][0]) == case["first_leaf"]

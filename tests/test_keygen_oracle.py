@@ -90,3 +90,16 @@ def test_library_shake256_is_fips202():
     from reef_amd import keygen
     for msg, n in ((b"", 32), (b"ck", 4096), (b"x" * 135, 137), (b"y" * 136, 272), (b"z" * 1000, 1), (b"w" * 137, 136)):
         assert keygen.shake256(msg, n) == hashlib.shake_256(msg).digest(n)
+
+
+def test_oracle_matches_committed_fixture():
+    """tests/golden/next_rows_golden.json (oracle/gen_golden_next_rows.py): the oracle's outputs on the stand-in parameter
+    sets, committed so that a change of the oracle shows up here (regression anchors, not reference vectors)."""
+    import json
+    import os
+    data = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "next_rows_golden.json")))
+    for case in data["keygen"]:
+        k = K.standin_params(case["curve"], case["root_index"], case["little_endian"])
+        assert hex(k.a) == case["a"] and hex(k.z) == case["z"]
+        pts = K.from_label(bytes.fromhex(case["label_hex"]), len(case["points"]), k)
+        assert [[hex(p[0]), hex(p[1])] for p in pts] == case["points"]

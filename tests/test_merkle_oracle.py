@@ -47,3 +47,15 @@ def test_permutation_is_a_permutation_and_sensitive():
     assert a != b and len(set(a)) == 5 and all(0 <= x < M.Q for x in a)
     # the MDS matrix is invertible (Cauchy): distinct rows, full rank over the field by construction 1/(x_i + y_j)
     assert all(p.mds[i][j] * (i + 5 + j) % M.Q == 1 for i in range(5) for j in range(5))
+
+
+def test_oracle_matches_committed_fixture():
+    """tests/golden/next_rows_golden.json (oracle/gen_golden_next_rows.py): regression anchors of the oracle on the stand-in
+    constants (not neptune's digests)."""
+    import json
+    import os
+    data = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "next_rows_golden.json")))
+    for case in data["merkle"]:
+        p = M.standin_params(M.Q if case["scalar_field_of"] == "pallas" else M.P, 5, case["rf"], case["rp"])
+        root, tree = M.commit(case["doc"], p)
+        assert hex(root) == case["root"] and [len(l) for l in tree] == case["level_sizes"] and hex(tree[0][0]) == case["first_leaf"]
