@@ -8,8 +8,8 @@ import time
 import numpy as np
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from oracle import mle_oracle, pasta_ref as R, sumcheck_oracle as S  # noqa: E402
-from reef_amd import mle, msm  # noqa: E402
+from oracle import keygen_oracle as KO, merkle_oracle as MO, mle_oracle, pasta_ref as R, sumcheck_oracle as S  # noqa: E402
+from reef_amd import keygen, merkle, mle, msm  # noqa: E402
 from reef_amd.sumcheck import SumCheck  # noqa: E402
 
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
@@ -18,7 +18,7 @@ t_end = time.time() + budget
 done = 0
 while time.time() < t_end:
     cid = int(rng.integers(0, 2))
-    shape = rng.integers(0, 7)
+    shape = rng.integers(0, 11)
     if shape == 0:      # single MSM, any size
         n = int(2 ** rng.uniform(0, 21.2 if os.environ.get("SOAK_BIG") else 18.5))
         kind = int(rng.integers(0, 3))
@@ -43,6 +43,46 @@ while time.time() < t_end:
                     parts.append(ctx.msm(sc[:m].copy()))
                 ctx.set_window_split(0, 1)
                 assert msm.compress(cid, msm.sum_points(cid, np.stack(parts))) == want, ("split", cid, n, m, world)
+    elif shape == 7:    # key derivation (stand-in parameter sets)
+        name = "pallas" if cid == 0 else "vesta"
+        k = KO.standin_params(name, int(rng.integers(0, 3)), bool(rng.integers(0, 2)))
+        label, n = rng.bytes(int(rng.integers(0, 40))), int(rng.integers(1, 48))
+        raw = keygen.derive_generators(name, label, n, k.a, k.b, k.z, k.iso, k.dst, k.little_endian)
+        assert keygen.points_to_ints(name, raw) == KO.from_label(label, n, k), ("keygen", name, n)
+    elif shape == 8:    # Poseidon Merkle tree (stand-in constants, any number of partial rounds)
+        p = MO.standin_params(MO.Q if cid == 0 else MO.P, 5, int(rng.choice([2, 4, 8])), int(rng.integers(0, 60)))
+        doc = [int(v) for v in rng.integers(0, 1 << 32, size=int(rng.integers(1, 120)), dtype=np.uint64)]
+        assert merkle.commit("pallas" if cid == 0 else "vesta", doc, p.t, p.rf, p.rp, p.rc, p.mds, p.tag_leaf, p.tag_node) == MO.commit(doc, p), ("merkle", cid, p.rf, p.rp, len(doc))
+    elif shape == 9:    # commitments over folded generators, folds recorded not performed
+        logn = int(rng.integers(1, 9))
+        n = 1 << logn
+        gens0 = R.gen_bases_ap(cid, int(rng.integers(1, 1 << 30)), 7, n)
+        order = S.Q if cid == 0 else mle_oracle.P
+        k = int(rng.integers(0, logn + 1))
+        w1s = [int.from_bytes(rng.bytes(32), "little") % order for _ in range(k)]
+        w2s = [int.from_bytes(rng.bytes(32), "little") % order for _ in range(k)]
+        gens = gens0
+        for a_, b_ in zip(w1s, w2s):
+            gens = R.fold(cid, np.ascontiguousarray(gens), a_, b_)
+        n_k = n >> k
+        off = int(rng.integers(0, n_k))
+        ln = int(rng.integers(1, n_k - off + 1))
+        v = R.gen_scalars(cid, int(rng.integers(1, 1 << 30)), ln)
+        with msm.MsmContext(cid, gens0, bucket_groups=int(rng.choice([0, 1]))) as ctx:
+            got = msm.compress(cid, ctx.msm_folded(v, w1s, w2s, off))
+        assert got == R.compress(cid, R.msm_pippenger(cid, np.ascontiguousarray(gens[off:off + ln]), v)), ("folded", cid, n, k, off, ln)
+    elif shape == 10:   # collisions everywhere: few distinct points (and their negatives), few distinct scalars
+        n = int(2 ** rng.uniform(1, 14))
+        distinct = R.gen_bases_ap(cid, int(rng.integers(1, 1 << 30)), 1, int(rng.integers(1, 4)))
+        C = __import__("oracle.pasta_oracle", fromlist=["CURVES"]).CURVES["pallas" if cid == 0 else "vesta"]
+        pool = [distinct[i].copy() for i in range(distinct.shape[0])]
+        pool += [np.frombuffer(C.affine_to_bytes(C.neg(C.affine_from_bytes(x.tobytes()))), dtype=np.uint64).copy() for x in pool]
+        bases = np.stack([pool[int(j)] for j in rng.integers(0, len(pool), size=n)])
+        few = R.gen_scalars(cid, int(rng.integers(1, 1 << 30)), 3)
+        sc = np.stack([few[int(j)] for j in rng.integers(0, 3, size=n)])
+        want = R.compress(cid, R.msm_pippenger(cid, bases, sc, threads=16))
+        with msm.MsmContext(cid, bases, bucket_groups=int(rng.choice([0, 1])), window_bits=int(rng.choice([0, 5, 13]))) as ctx:
+            assert msm.compress(cid, ctx.msm(sc)) == want, ("collide", cid, n)
     elif shape == 1:    # stateless drop-in symbol
         n = int(2 ** rng.uniform(0, 16))
         bases = R.gen_bases_ap(cid, int(rng.integers(1, 1 << 30)), 3, n)
