@@ -353,7 +353,8 @@ reef_status reef_msm_plan_for(size_t n, uint32_t window_bits, uint32_t bucket_gr
 reef_status reef_test_field_op(int field, int op, const reef_fe *a, const reef_fe *b, reef_fe *out, size_t n);
 /* op: 0 mixed add P+Q, 1 general add, 2 double P, 3 k*P (k canonical in kbuf); the four-wave forms of the tail
  * kernels: 4 general add, 5 double, 6 the chain 4*(P + Q) + P, 7-10 latency probes, 11-19 every back-to-back order
- * of additions and doublings. */
+ * of additions and doublings, 20 a doubling followed by an addition that falls into its own doubling (4P), 21 an addition
+ * of Z = 1 operands, 22 a step machine with one addition site and one doubling site (7*(P + Q)). */
 reef_status reef_test_ec_op(int curve, int op, const reef_affine *p, const reef_affine *q, const reef_fe *k,
                             reef_jacobian *out, size_t n);
 /* Field-multiplication throughput probe: returns Montgomery products per second. */
