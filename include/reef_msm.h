@@ -82,13 +82,18 @@ typedef struct {
                                (all windows share one bucket set); otherwise windows w and w'
                                share buckets iff w % G == w' % G */
     uint32_t chunk;         /* sorted entries per accumulation thread (L0); 0 = default */
-    uint32_t segment;       /* reserved, ignored */
+    uint32_t byte_tables;   /* bucket_groups = 1, 1024 < n <= 65536: the sort-free byte tables (256 KiB per point, built in
+                               35-70 ms): 0 = once the key has served REEF_MSM_WIDE_AFTER MSMs (default 64), 1 = at
+                               creation, 2 = never.  See reef_msm_ctx_byte_tables. */
     int32_t device;         /* HIP device ordinal; -1 = current device */
     uint32_t reserved[3];
 } reef_msm_opts;
 
 reef_status reef_msm_ctx_create(reef_msm_ctx **out, int curve, const reef_affine *bases, size_t n,
                                 int bases_loc, const reef_msm_opts *opts /* may be NULL */);
+/* 1 when MSMs on this key are served from its byte tables (a mid-size resident key: every signed byte multiple of every point
+ * tabulated, an MSM is a plain sum of table entries: no sort, no buckets; 2^15 points 0.19 ms against 0.32 ms), else 0. */
+int reef_msm_ctx_byte_tables(reef_msm_ctx *ctx);
 /* Replace the key of a ctx in place (same options, workspace kept): what the IPA rounds need, where
  * the generators change every round (CommitmentGens::fold [R], framework.rs:695).  Fails on a ctx
  * whose key is shared with clones. */

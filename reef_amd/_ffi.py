@@ -27,7 +27,7 @@ class ReefError(RuntimeError):
 
 
 class MsmOpts(ctypes.Structure):
-    _fields_ = [("window_bits", c_uint32), ("bucket_groups", c_uint32), ("chunk", c_uint32), ("segment", c_uint32),
+    _fields_ = [("window_bits", c_uint32), ("bucket_groups", c_uint32), ("chunk", c_uint32), ("byte_tables", c_uint32),
                 ("device", c_int32), ("reserved", c_uint32 * 3)]
 
 
@@ -87,6 +87,7 @@ def load() -> ctypes.CDLL:
         "reef_msm_ctx_timing_stats": (c_int, [vp, c_int, POINTER(c_uint64), POINTER(c_double), POINTER(c_double)]),
         "reef_msm_ctx_sum_points": (c_int, [vp, vp, c_size_t, vp]),
         "reef_msm_ctx_plan": (c_int, [vp, POINTER(c_uint32), POINTER(c_uint32), POINTER(c_uint32), POINTER(c_uint32)]),
+        "reef_msm_ctx_byte_tables": (c_int, [vp]),
         "reef_msm_plan_for": (c_int, [c_size_t, c_uint32, c_uint32, POINTER(c_uint32), POINTER(c_uint32), POINTER(c_uint32),
                                       POINTER(c_uint32)]),
         "reef_msm_folded": (c_int, [vp, vp, c_size_t, c_size_t, c_int, c_bool, vp, vp, c_size_t, vp, c_int]),

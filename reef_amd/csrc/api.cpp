@@ -183,6 +183,7 @@ reef_status reef_msm_rows(reef_msm_ctx *ctx, const reef_fe *scalars, size_t rows
     return guarded([&] { return vt(ctx->curve)->msm_rows(ctx->impl, scalars, rows, row_len, scalars_loc, is_mont, max_scalar_bits, blinds, h, out, out_loc); });
 }
 
+int reef_msm_ctx_byte_tables(reef_msm_ctx *ctx) { return ctx ? vt(ctx->curve)->ctx_byte_tables(ctx->impl) : 0; }
 reef_status reef_msm_plan_for(size_t n, uint32_t window_bits, uint32_t bucket_groups, uint32_t *c, uint32_t *windows,
                               uint32_t *groups, uint32_t *tables) {
     return pallas_vtable()->plan_for(n, window_bits, bucket_groups, c, windows, groups, tables);

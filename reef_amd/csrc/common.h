@@ -59,6 +59,7 @@ struct CurveVTable {
     reef_status (*ctx_timing_stats)(void *impl, int reset, uint64_t *calls, double *total_ms, double *acc_ms);
     reef_status (*ctx_sum_points)(void *impl, const reef_jacobian *in, size_t n, reef_jacobian *out);
     reef_status (*ctx_plan)(void *impl, uint32_t *c, uint32_t *w, uint32_t *g, uint32_t *t);
+    int (*ctx_byte_tables)(void *impl);
     reef_status (*msm)(void *impl, const reef_fe *scalars, size_t n, int loc, bool is_mont, reef_jacobian *out, int out_loc);
     reef_status (*msm_rows)(void *impl, const reef_fe *scalars, size_t rows, size_t row_len, int loc, bool is_mont,
                             uint32_t max_bits, const reef_fe *blinds, const reef_affine *h, reef_jacobian *out, int out_loc);

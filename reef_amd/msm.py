@@ -88,7 +88,7 @@ class MsmContext:
     """A resident commitment key (nova-snark `CommitmentGens<G>`) on one GPU."""
 
     def __init__(self, curve, bases: Buf, n: Optional[int] = None, *, window_bits: int = 0, bucket_groups: int = 0,
-                 chunk: int = 0, device: int = -1, _handle=None):
+                 chunk: int = 0, device: int = -1, byte_tables: int = 0, _handle=None):
         self.curve = curve_id(curve)
         self._lib = _ffi.load()
         if _handle is not None:
@@ -100,7 +100,7 @@ class MsmContext:
                 raise ValueError("n is required for device-resident bases")
             n = bases.shape[0]
         loc, ptr = _loc_ptr(bases, 64 * n)
-        opts = MsmOpts(window_bits, bucket_groups, chunk, 0, device, (ctypes.c_uint32 * 3)(0, 0, 0))
+        opts = MsmOpts(window_bits, bucket_groups, chunk, byte_tables, device, (ctypes.c_uint32 * 3)(0, 0, 0))
         h = ctypes.c_void_p()
         check(self._lib.reef_msm_ctx_create(ctypes.byref(h), self.curve, ptr, n, loc, ctypes.byref(opts)))
         self._h = h
@@ -147,6 +147,10 @@ class MsmContext:
         c, w, g, t = (ctypes.c_uint32() for _ in range(4))
         check(self._lib.reef_msm_ctx_plan(self._h, ctypes.byref(c), ctypes.byref(w), ctypes.byref(g), ctypes.byref(t)))
         return {"window_bits": c.value, "windows": w.value, "bucket_groups": g.value, "tables": t.value}
+
+    def has_byte_tables(self) -> bool:
+        """True when this key's MSMs are served from its byte tables (byte_tables=1 at creation, or earned: reef_msm.h)."""
+        return bool(self._lib.reef_msm_ctx_byte_tables(self._h))
 
     def set_window_split(self, rank: int, world: int) -> None:
         """This context accumulates only the windows w = rank (mod world): its MSMs return partial sums."""

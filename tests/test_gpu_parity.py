@@ -583,3 +583,98 @@ def test_bench_collective_path_on_one_gpu(gpu_lib):
     assert line["roofline"]["achieved"] > 0 and line["roofline"]["kernel_ms"] > 0
 
 
+
+
+# ---------------------------------------------------------------- byte tables (mid-size resident keys) ----
+@pytest.mark.parametrize("name", ["pallas", "vesta"])
+def test_byte_tables_match_oracle(name, gpu_lib, cref):
+    """The sort-free path over byte tables (bucket_groups = 1, byte_tables = 1): every scalar shape, ragged lengths, both
+    scalar conventions, identity points, colliding points, and scalars whose bytes sit on the recoding edges."""
+    from reef_amd import msm
+    cid = CID[name]
+    C = CURVES[name]
+    rng = SplitMix64(2718)
+    n = 3001
+    bases = cref.gen_bases_ap(cid, 77, 5, n)
+    bases[7] = 0
+    bases[100] = bases[101]                                                     # P + P inside one window
+    bases[200] = np.frombuffer(C.affine_to_bytes(C.neg(C.affine_from_bytes(bases[201].tobytes()))), dtype=np.uint64)
+    with msm.MsmContext(cid, bases, bucket_groups=1, byte_tables=1) as ctx:
+        assert ctx.has_byte_tables()
+        for kind, bound in ((0, 0), (1, 0), (2, 131)):
+            sc = cref.gen_scalars(cid, 5 + kind, n, kind=kind, small_bound=bound)
+            sc[100] = sc[101]
+            sc[200] = sc[201]
+            for m in (n, 1, 2, 1025, 2999):
+                want = cref.compress(cid, cref.msm_pippenger(cid, bases[:m].copy(), sc[:m].copy()))
+                assert msm.compress(cid, ctx.msm(sc[:m].copy())) == want, (kind, m)
+            canon = cref.gen_scalars(cid, 5 + kind, n, kind=kind, small_bound=bound, mont=False)
+            canon[100] = canon[101]
+            canon[200] = canon[201]
+            assert msm.compress(cid, ctx.msm(canon, is_mont=False)) == cref.compress(cid, cref.msm_pippenger(cid, bases, sc))
+        # bytes on the edges of the signed recoding: 0x80 (kept), 0x81 (negative with a carry), 0xff runs (carry chains), r - 1
+        r = C.order
+        edge = [0, 1, 0x80, 0x81, 0xFF, 0x100, 0x7F80, 0x8080, 0x80FF, (1 << 254) - 1, (1 << 254), r - 1, r - 2,
+                int("80" * 31, 16), int("81" * 31, 16), int("7f" + "ff" * 30, 16), int("ff" * 31, 16) % r]
+        vals = [edge[j % len(edge)] if j < 4 * len(edge) else uniform_scalar(rng, r) for j in range(n)]
+        sc = np.array([[(v >> (64 * j)) & 0xFFFFFFFFFFFFFFFF for j in range(4)] for v in vals], dtype=np.uint64)
+        acc = None
+        pts = [C.affine_from_bytes(bases[i].tobytes()) for i in range(4 * len(edge))]
+        for v, p in zip(vals, pts):
+            acc = C.add(acc, C.mul(v, p))
+        got = ctx.msm(sc[:4 * len(edge)].copy(), is_mont=False)
+        assert msm.compress(cid, got) == C.compress(acc)
+
+
+@pytest.mark.parametrize("name,logn,kind", [("pallas", 15, 0), ("pallas", 16, 0), ("vesta", 14, 1), ("pallas", 16, 1)])
+def test_byte_tables_at_prover_sizes_dlog_property(name, logn, kind, gpu_lib):
+    """Reef's own key sizes (2^14 .. 2^16) through the byte tables: bases in arithmetic progression, so the result is
+    (sum_i s_i*(k0 + i*d)) * G; the bucket pipeline on the same key (byte_tables = 2) must give the same point."""
+    from reef_amd import msm
+    C = CURVES[name]
+    n = 1 << logn
+    k0, d = 0xFEDCBA, 0x7531
+    bases = msm.gen_bases(name, k0, d, n, device=True)
+    sc_dev = msm.gen_scalars(name, 0xACE, n, kind=kind, mont=True, device=True)
+    canon = msm.gen_scalars(name, 0xACE, n, kind=kind, mont=False)
+    with msm.MsmContext(name, bases, n, bucket_groups=1, byte_tables=1) as ctx, msm.MsmContext(name, bases, n, bucket_groups=1, byte_tables=2) as ref:
+        assert ctx.has_byte_tables() and not ref.has_byte_tables()
+        got = ctx.msm(sc_dev, n)
+        assert msm.compress(name, got) == msm.compress(name, ref.msm(sc_dev, n))
+        m = n - 12345                                                          # a ragged prefix of the key
+        got_m = ctx.msm(sc_dev, m)
+    cols = [canon[:, j].astype(object) for j in range(4)]
+    idx = np.arange(n, dtype=object)
+
+    def dlog(upto):
+        acc = 0
+        for j in range(4):
+            acc += (int(np.sum(cols[j][:upto])) * k0 + int(np.sum(cols[j][:upto] * idx[:upto])) * d) << (64 * j)
+        return C.compress(C.mul(acc % C.order, C.gen))
+    assert msm.compress(name, got) == dlog(n)
+    assert msm.compress(name, got_m) == dlog(m)
+
+
+def test_byte_tables_are_earned_by_default(gpu_lib, cref):
+    """Default policy: a key builds its byte tables when it has served REEF_MSM_WIDE_AFTER (64) MSMs; results do not change."""
+    import os
+    from reef_amd import msm
+    if os.environ.get("REEF_MSM_WIDE_AFTER"):
+        pytest.skip("policy overridden by the environment")
+    cid, n = 0, 2048
+    bases = cref.gen_bases_ap(cid, 9, 2, n)
+    sc = cref.gen_scalars(cid, 4, n)
+    want = cref.compress(cid, cref.msm_pippenger(cid, bases, sc))
+    with msm.MsmContext(cid, bases, bucket_groups=1) as ctx:
+        clone = ctx.clone()
+        for k in range(63):
+            assert not ctx.has_byte_tables()
+            assert msm.compress(cid, (ctx if k % 2 else clone).msm(sc)) == want
+        assert msm.compress(cid, clone.msm(sc)) == want                        # the 64th call on the shared key builds them
+        assert ctx.has_byte_tables() and clone.has_byte_tables()
+        assert msm.compress(cid, ctx.msm(sc)) == want
+        clone.close()
+    with msm.MsmContext(cid, bases[:1000].copy(), bucket_groups=1, byte_tables=1) as small:   # <= 1024 points: the nibble tables serve it
+        assert not small.has_byte_tables()
+    with msm.MsmContext(cid, bases, bucket_groups=0, byte_tables=1) as plain:               # not pre-shifted: no tables
+        assert not plain.has_byte_tables()

@@ -33,7 +33,7 @@ def show(path):
     rows = list(csv.DictReader(open(path)))
     rows.sort(key=lambda r: int(r["Start_Timestamp"]))
     # the last MSM = from the last k_recode on
-    last = max(i for i, r in enumerate(rows) if "k_recode" in r["Kernel_Name"])
+    last = max(i for i, r in enumerate(rows) if "recode" in r["Kernel_Name"])
     seq = rows[last:]
     t0 = int(seq[0]["Start_Timestamp"])
     prev_end = t0
