@@ -117,9 +117,10 @@ def test_ipa_without_generator_folding(groups, gpu_lib, cref):
             w2s.append(w2)
 
 
-def test_ipa_cross_terms_at_prover_size_dlog_property(gpu_lib):
+@pytest.mark.parametrize("byte_tables", [2, 1])
+def test_ipa_cross_terms_at_prover_size_dlog_property(byte_tables, gpu_lib):
     """The L/R batch at the size of Reef's final IPA (2^16 generators: the batch goes through the two-level
-    sort).  Generators in arithmetic progression, so a cross term is (sum_j s[j] * (k0 + j*d)) * G with the
+    sort, or -- byte_tables = 1 -- both terms come from one pass over the byte tables).  Generators in arithmetic progression, so a cross term is (sum_j s[j] * (k0 + j*d)) * G with the
     expanded scalars of the definition: s_L[j] = a[i - n_k/2] * coef[t] on the upper half of block t,
     s_R[j] = a[i + n_k/2] * coef[t] on the lower half, coef[t] = prod_m (bit_{k-1-m}(t) ? w2_m : w1_m)."""
     from reef_amd import msm
@@ -130,7 +131,8 @@ def test_ipa_cross_terms_at_prover_size_dlog_property(gpu_lib):
     rng = SplitMix64(2025)
     a_canon = msm.gen_scalars("pallas", 31, n, mont=False)
     a_int = [sum(int(a_canon[i, j]) << (64 * j) for j in range(4)) for i in range(n)]
-    with msm.MsmContext("pallas", gens, bucket_groups=1) as ctx:
+    with msm.MsmContext("pallas", gens, bucket_groups=1, byte_tables=byte_tables) as ctx:
+        assert ctx.has_byte_tables() == (byte_tables == 1)
         w1s, w2s = [], []
         for k in range(0, 4):
             n_k, half = n >> k, n >> (k + 1)
@@ -288,3 +290,33 @@ def test_lazy_fold_serves_the_whole_ipa(groups, gpu_lib, cref):
     with pytest.raises(ValueError):
         P.FoldedGens(root, [1], [2], 60, 10)
     root.close()
+
+
+def test_ipa_cross_terms_on_byte_tables(gpu_lib, cref):
+    """reef_ipa_cross_terms on a key with byte tables: both cross terms from ONE pass over the table entries (each point feeds
+    exactly one of them) == fold the generators k times (oracle), then the two cross MSMs."""
+    from reef_amd import msm
+    cid = 0
+    C = CURVES["pallas"]
+    n = 2048
+    gens0 = cref.gen_bases_ap(cid, 51, 3, n)
+    rng = SplitMix64(1234)
+    with msm.MsmContext(cid, gens0, bucket_groups=1, byte_tables=1) as ctx:
+        assert ctx.has_byte_tables()
+        gens = gens0
+        w1s, w2s = [], []
+        a = cref.gen_scalars(cid, 8, n)
+        a[5] = 0
+        for k in range(0, 9):
+            n_k = n >> k
+            half = n_k // 2
+            a_k = a[:n_k].copy()
+            L, R = ctx.ipa_cross_terms(a_k, w1s, w2s)
+            exp_l = cref.msm_pippenger(cid, np.ascontiguousarray(gens[half:n_k]), a_k[:half].copy())
+            exp_r = cref.msm_pippenger(cid, np.ascontiguousarray(gens[:half]), a_k[half:].copy())
+            assert msm.compress(cid, L) == cref.compress(cid, exp_l), k
+            assert msm.compress(cid, R) == cref.compress(cid, exp_r), k
+            w1, w2 = uniform_scalar(rng, C.order), uniform_scalar(rng, C.order)
+            gens = cref.fold(cid, np.ascontiguousarray(gens[:n_k]), w1, w2)
+            w1s.append(w1)
+            w2s.append(w2)
