@@ -255,12 +255,16 @@ int main(int argc, char **argv) {
     for (const Shape &s : SHAPES)
         if (strstr(s.name, which)) sh = &s;
     if (!sh) {
-        fprintf(stderr, "usage: reef_replay [cfg1|cfg3|cfg4|cfg5] [nofold]\n");
+        fprintf(stderr, "usage: reef_replay [cfg1|cfg3|cfg4|cfg5] [nofold] [tables]\n");
         return 2;
     }
     if (reef_device_count() < 1) { fprintf(stderr, "no GPU: %s\n", reef_last_error()); return 3; }
 
-    const bool nofold = argc > 2 && strcmp(argv[2], "nofold") == 0;
+    bool nofold = false, tables = false;
+    for (int i = 2; i < argc; ++i) {
+        if (strcmp(argv[i], "nofold") == 0) nofold = true;
+        else if (strcmp(argv[i], "tables") == 0) tables = true;       // a long-lived prover: the keys have earned their byte tables
+    }
     Curve cv[2];
     cv[0].id = REEF_PALLAS; cv[0].n = next_pow2(sh->w1 > sh->c1 ? sh->w1 : sh->c1);
     cv[1].id = REEF_VESTA;  cv[1].n = next_pow2(sh->w2 > sh->c2 ? sh->w2 : sh->c2);
@@ -282,6 +286,7 @@ int main(int argc, char **argv) {
         }
         reef_msm_opts o = {};
         o.bucket_groups = 1;  // commitment keys are fixed for the life of PublicParams: pre-shift once
+        o.byte_tables = tables ? 1 : 2;   // explicit, so that the default policy (tables after 64 MSMs on a key) cannot switch paths mid-run
         o.device = -1;
         t0 = clk::now();
         CK(reef_msm_ctx_create(&c.key, c.id, c.d_gens, c.n, REEF_DEVICE, &o));
@@ -388,6 +393,7 @@ int main(int argc, char **argv) {
         if (nofold) {   // the Hyrax row generators are a resident key of their own (commitment.rs:176-186)
             reef_msm_opts o = {};
             o.bucket_groups = 1;
+            o.byte_tables = tables ? 1 : 2;
             o.device = -1;
             CK(reef_msm_ctx_create(&hy.key, hy.id, hy.d_gens, hy.n, REEF_DEVICE, &o));
             reef_jacobian warm_l, warm_r;
@@ -473,10 +479,11 @@ int main(int argc, char **argv) {
            "\"ipa_vesta_rounds\": %d, \"consistency_ipa_ms\": %.3f, \"consistency_rounds\": %d, \"total_prove_msm_ms\": %.3f, "
            "\"commit_hyrax_ms\": %.3f, \"commit_hyrax_first_call_ms\": %.3f, \"sumcheck_table_log\": %d, \"sumcheck_ms_per_step\": %.3f, "
            "\"doc_poly_bind_rows_ms\": %.3f, \"total_prove_gpu_ms\": %.3f, \"derive_both_keys_ms\": %.3f, \"commit_merkle_log\": %d, \"commit_merkle_ms\": %.3f, "
-           "\"standins\": \"key derivation and Poseidon run on stand-in parameter sets (replay_standins.h), timing only\"}\n",
+           "\"standins\": \"key derivation and Poseidon run on stand-in parameter sets (replay_standins.h), timing only\", \"byte_tables\": %s}\n",
            sh->name, nofold ? "cross terms over the original key (no generator fold)" : "generator fold per round", g_checked, cv[0].n, cv[1].n, sh->steps, setup_ms, steps_ms, steps_ms / sh->steps, steps_batched_ms / sh->steps, pairs_step, final_ms, ipa1_ms, r1, ipa2_ms, r2,
            cons_ms, r3, steps_ms + final_ms + cons_ms, commit_ms, commit_first_ms, sh->table_log, sc_step_ms, mle_ms,
-           steps_ms + final_ms + cons_ms + sh->steps * sc_step_ms + mle_ms, derive_ms, sh->merkle_log, merkle_ms);
+           steps_ms + final_ms + cons_ms + sh->steps * sc_step_ms + mle_ms, derive_ms, sh->merkle_log, merkle_ms,
+           tables ? "\"built with the keys (inside setup_ms): MSMs of 1025..65536 points are sums of table entries\"" : "\"none (bucket pipeline)\"");
     for (Curve &c : cv) {
         reef_msm_ctx_destroy(c.key);
         reef_msm_ctx_destroy(c.one);
