@@ -612,6 +612,12 @@ def test_byte_tables_match_oracle(name, gpu_lib, cref):
             canon[100] = canon[101]
             canon[200] = canon[201]
             assert msm.compress(cid, ctx.msm(canon, is_mont=False)) == cref.compress(cid, cref.msm_pippenger(cid, bases, sc))
+        # CE::commit(v, blind) on the same key: v*G from the byte tables + blind*H
+        sc = cref.gen_scalars(cid, 21, n)
+        bl = cref.gen_scalars(cid, 22, 1)
+        h = cref.gen_bases_ap(cid, 0xB11D, 1, 1)[0].copy()
+        want = cref.compress(cid, cref.row_msm(cid, bases, sc, 1, n, h=h, blinds=bl, threads=4))
+        assert msm.compress(cid, ctx.msm_rows(sc, 1, n, blinds=bl, h=h)) == want
         # bytes on the edges of the signed recoding: 0x80 (kept), 0x81 (negative with a carry), 0xff runs (carry chains), r - 1
         r = C.order
         edge = [0, 1, 0x80, 0x81, 0xFF, 0x100, 0x7F80, 0x8080, 0x80FF, (1 << 254) - 1, (1 << 254), r - 1, r - 2,

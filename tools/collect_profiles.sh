@@ -12,6 +12,8 @@ python $root/tools/time_small.py > $out/${R}_small_msm_latency.txt 2>&1
 for c in cfg1 cfg3 cfg4 cfg5; do $root/reef_amd/_lib/reef_replay $c nofold; done > $out/${R}_replay_prove_msm.jsonl 2>/dev/null
 $root/reef_amd/_lib/reef_replay cfg3 >> $out/${R}_replay_prove_msm.jsonl 2>/dev/null
 $root/reef_amd/_lib/reef_replay cfg4 >> $out/${R}_replay_prove_msm.jsonl 2>/dev/null
+for c in cfg1 cfg3 cfg4 cfg5; do $root/reef_amd/_lib/reef_replay $c nofold tables; done >> $out/${R}_replay_prove_msm.jsonl 2>/dev/null
+python $root/tools/time_ipa.py 14 15 16 > $out/${R}_ipa_round_timing.txt 2>&1
 for cfg in "15 13 1" "16 15 1" "20 17 1"; do $root/tools/prof_cfg.sh /tmp/tr $cfg 0 both; done
 cat /tmp/tr/trace_*.txt > $out/${R}_msm_kernel_timelines.txt
 (cd /tmp && rm -rf /tmp/pp && rocprofv3 --kernel-trace --output-format csv -d /tmp/pp -- python $root/tools/coop_probe.py > /dev/null 2>&1; python - <<PY > $out/${R}_group_op_latency.txt

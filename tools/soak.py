@@ -29,7 +29,8 @@ while time.time() < t_end:
             sc[rng.integers(0, n, size=3)] = 0
         want = R.compress(cid, R.msm_pippenger(cid, bases, sc, threads=16))
         groups = int(rng.choice([0, 1, 1, 3]))
-        with msm.MsmContext(cid, bases, bucket_groups=groups, window_bits=int(rng.choice([0, 0, 7, 13, 15, 16]))) as ctx:
+        with msm.MsmContext(cid, bases, bucket_groups=groups, window_bits=int(rng.choice([0, 0, 7, 13, 15, 16])),
+                            byte_tables=int(rng.choice([1, 1, 2])) if n <= 65536 else 0) as ctx:
             m = int(rng.integers(1, n + 1)) if rng.random() < 0.3 else n
             got = msm.compress(cid, ctx.msm(sc[:m].copy()))
             if m != n:
@@ -54,7 +55,7 @@ while time.time() < t_end:
         doc = [int(v) for v in rng.integers(0, 1 << 32, size=int(rng.integers(1, 120)), dtype=np.uint64)]
         assert merkle.commit("pallas" if cid == 0 else "vesta", doc, p.t, p.rf, p.rp, p.rc, p.mds, p.tag_leaf, p.tag_node) == MO.commit(doc, p), ("merkle", cid, p.rf, p.rp, len(doc))
     elif shape == 9:    # commitments over folded generators, folds recorded not performed
-        logn = int(rng.integers(1, 9))
+        logn = int(rng.integers(1, 13))
         n = 1 << logn
         gens0 = R.gen_bases_ap(cid, int(rng.integers(1, 1 << 30)), 7, n)
         order = S.Q if cid == 0 else mle_oracle.P
@@ -68,7 +69,7 @@ while time.time() < t_end:
         off = int(rng.integers(0, n_k))
         ln = int(rng.integers(1, n_k - off + 1))
         v = R.gen_scalars(cid, int(rng.integers(1, 1 << 30)), ln)
-        with msm.MsmContext(cid, gens0, bucket_groups=int(rng.choice([0, 1]))) as ctx:
+        with msm.MsmContext(cid, gens0, bucket_groups=int(rng.choice([0, 1])), byte_tables=int(rng.choice([1, 2]))) as ctx:
             got = msm.compress(cid, ctx.msm_folded(v, w1s, w2s, off))
         assert got == R.compress(cid, R.msm_pippenger(cid, np.ascontiguousarray(gens[off:off + ln]), v)), ("folded", cid, n, k, off, ln)
     elif shape == 10:   # collisions everywhere: few distinct points (and their negatives), few distinct scalars
@@ -81,7 +82,7 @@ while time.time() < t_end:
         few = R.gen_scalars(cid, int(rng.integers(1, 1 << 30)), 3)
         sc = np.stack([few[int(j)] for j in rng.integers(0, 3, size=n)])
         want = R.compress(cid, R.msm_pippenger(cid, bases, sc, threads=16))
-        with msm.MsmContext(cid, bases, bucket_groups=int(rng.choice([0, 1])), window_bits=int(rng.choice([0, 5, 13]))) as ctx:
+        with msm.MsmContext(cid, bases, bucket_groups=int(rng.choice([0, 1])), window_bits=int(rng.choice([0, 5, 13])), byte_tables=int(rng.choice([1, 2]))) as ctx:
             assert msm.compress(cid, ctx.msm(sc)) == want, ("collide", cid, n)
     elif shape == 1:    # stateless drop-in symbol
         n = int(2 ** rng.uniform(0, 16))
