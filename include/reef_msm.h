@@ -82,9 +82,10 @@ typedef struct {
                                (all windows share one bucket set); otherwise windows w and w'
                                share buckets iff w % G == w' % G */
     uint32_t chunk;         /* sorted entries per accumulation thread (L0); 0 = default */
-    uint32_t byte_tables;   /* bucket_groups = 1, 1024 < n <= 65536: the sort-free byte tables (256 KiB per point, built in
-                               35-70 ms): 0 = once the key has served REEF_MSM_WIDE_AFTER MSMs (default 64), 1 = at
-                               creation, 2 = never.  See reef_msm_ctx_byte_tables. */
+    uint32_t byte_tables;   /* bucket_groups = 1, 1024 < n <= 65536: the sort-free byte tables (256 KiB per point).  0 = built in
+                               the background from reef_msm_ctx_create on (14-38 ms on a low-priority stream; the bucket
+                               pipeline serves the key until they are ready), 1 = reef_msm_ctx_create returns when they
+                               are ready, 2 = none.  See reef_msm_ctx_byte_tables. */
     int32_t device;         /* HIP device ordinal; -1 = current device */
     uint32_t reserved[3];
 } reef_msm_opts;

@@ -661,25 +661,39 @@ def test_byte_tables_at_prover_sizes_dlog_property(name, logn, kind, gpu_lib):
     assert msm.compress(name, got_m) == dlog(m)
 
 
-def test_byte_tables_are_earned_by_default(gpu_lib, cref):
-    """Default policy: a key builds its byte tables when it has served REEF_MSM_WIDE_AFTER (64) MSMs; results do not change."""
+def test_byte_tables_are_built_in_the_background_by_default(gpu_lib, cref):
+    """Default policy: the tables of an eligible key are built on a stream of their own from reef_msm_ctx_create on; the bucket
+    pipeline serves the key meanwhile, the switch changes no result, clones share the tables, re-keying drops them."""
     import os
+    import time
     from reef_amd import msm
-    if os.environ.get("REEF_MSM_WIDE_AFTER"):
-        pytest.skip("policy overridden by the environment")
-    cid, n = 0, 2048
+    if os.environ.get("REEF_MSM_WIDE") == "0":
+        pytest.skip("byte tables switched off by the environment")
+    cid, n = 0, 16384
     bases = cref.gen_bases_ap(cid, 9, 2, n)
     sc = cref.gen_scalars(cid, 4, n)
-    want = cref.compress(cid, cref.msm_pippenger(cid, bases, sc))
+    want = cref.compress(cid, cref.msm_pippenger(cid, bases, sc, threads=8))
     with msm.MsmContext(cid, bases, bucket_groups=1) as ctx:
         clone = ctx.clone()
-        for k in range(63):
-            assert not ctx.has_byte_tables()
-            assert msm.compress(cid, (ctx if k % 2 else clone).msm(sc)) == want
-        assert msm.compress(cid, clone.msm(sc)) == want                        # the 64th call on the shared key builds them
-        assert ctx.has_byte_tables() and clone.has_byte_tables()
-        assert msm.compress(cid, ctx.msm(sc)) == want
+        seen = set()
+        deadline = time.time() + 20
+        while time.time() < deadline:                                         # calls before, during and after the build
+            seen.add(ctx.has_byte_tables())
+            assert msm.compress(cid, (ctx if len(seen) % 2 else clone).msm(sc)) == want
+            if True in seen:
+                break
+        assert True in seen, "the tables never became ready"
+        assert clone.has_byte_tables()
+        assert msm.compress(cid, clone.msm(sc)) == want and msm.compress(cid, ctx.msm(sc[:5000].copy())) == cref.compress(
+            cid, cref.msm_pippenger(cid, bases[:5000].copy(), sc[:5000].copy()))
         clone.close()
+        bases2 = cref.gen_bases_ap(cid, 77, 3, n)                              # re-keying: the old tables must not serve the new key
+        ctx.set_bases(bases2)
+        assert msm.compress(cid, ctx.msm(sc)) == cref.compress(cid, cref.msm_pippenger(cid, bases2, sc, threads=8))
+    with msm.MsmContext(cid, bases, bucket_groups=1, byte_tables=2) as none:
+        assert msm.compress(cid, none.msm(sc)) == want and not none.has_byte_tables()
+    with msm.MsmContext(cid, bases, bucket_groups=1) as gone:               # destroyed while the build is in flight
+        pass
     with msm.MsmContext(cid, bases[:1000].copy(), bucket_groups=1, byte_tables=1) as small:   # <= 1024 points: the nibble tables serve it
         assert not small.has_byte_tables()
     with msm.MsmContext(cid, bases, bucket_groups=0, byte_tables=1) as plain:               # not pre-shifted: no tables

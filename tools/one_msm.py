@@ -9,7 +9,7 @@ n = 1 << logn
 bases = msm.gen_bases("pallas", 12345, 7, n, device=True)
 sc = msm.gen_scalars("pallas", 99, n, kind=0, device=True)
 out = msm.DeviceBuffer(96)
-ctx = msm.MsmContext("pallas", bases, n, window_bits=c, bucket_groups=g)
+ctx = msm.MsmContext("pallas", bases, n, window_bits=c, bucket_groups=g, byte_tables=2)
 ctx.enable_timing(True)
 for _ in range(reps):
     ctx.msm(sc, n, out=out)

@@ -16,7 +16,7 @@ def run(logn, c, g, reps=8, kind=0, chunk=0):
     bases = msm.gen_bases("pallas", 12345, 7, n, device=True)
     sc = msm.gen_scalars("pallas", 99, n, kind=kind, device=True)
     out = msm.DeviceBuffer(96)
-    ctx = msm.MsmContext("pallas", bases, n, window_bits=c, bucket_groups=g, chunk=chunk)
+    ctx = msm.MsmContext("pallas", bases, n, window_bits=c, bucket_groups=g, chunk=chunk, byte_tables=int(os.environ.get("BYTE_TABLES", "2")))
     ctx.enable_timing(True)
     for _ in range(3):
         ctx.msm(sc, n, out=out)

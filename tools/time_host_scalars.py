@@ -7,10 +7,11 @@ import numpy as np
 import torch
 from reef_amd import msm
 
-logn = int(sys.argv[1]) if len(sys.argv) > 1 else 20
+logn = int([a for a in sys.argv[1:] if a.isdigit()][0]) if [a for a in sys.argv[1:] if a.isdigit()] else 20
 n = 1 << logn
 bases = msm.gen_bases("pallas", 11, 3, n, device=True)
-ctx0 = msm.MsmContext("pallas", bases, n, bucket_groups=1)
+tables = 1 if "--tables" in sys.argv else 2          # byte tables (keys of at most 2^16 points) or the bucket pipeline
+ctx0 = msm.MsmContext("pallas", bases, n, bucket_groups=1, byte_tables=tables)
 sc = msm.gen_scalars("pallas", 5, n)
 pin = torch.empty((n, 4), dtype=torch.int64, pin_memory=True)
 pin.copy_(torch.from_numpy(np.asarray(sc).view(np.int64)))

@@ -11,7 +11,7 @@ for n in (1, 2, 16, 128, 512, 1024, 2048):
     sc = msm.gen_scalars("pallas", 9, n)
     dsc = msm.DeviceBuffer.from_host(sc)
     dout = msm.DeviceBuffer(96)
-    with msm.MsmContext("pallas", bases, n, bucket_groups=1) as ctx:
+    with msm.MsmContext("pallas", bases, n, bucket_groups=1, byte_tables=2) as ctx:
         ctx.enable_timing(True)
         for _ in range(3): ctx.msm(dsc, n, out=dout)
         ctx.sync(); ctx.timing_stats(reset=True)
