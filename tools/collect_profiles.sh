@@ -34,3 +34,4 @@ python $root/tools/time_mle.py > $out/${R}_mle_timing.txt 2>&1
 (python $root/tools/time_merkle.py; echo "# REEF_POSEIDON_DENSE=1 (partial rounds in the defining dense form), same box:"; REEF_POSEIDON_DENSE=1 python $root/tools/time_merkle.py | grep symbols) > $out/${R}_merkle_timing.txt 2>&1
 python $root/tools/time_keygen.py $out/${R}_keygen_timing.json > /dev/null 2>&1
 python $root/tools/time_setup.py $out/${R}_setup_timing.json > /dev/null 2>&1
+(python $root/tools/time_host_scalars.py 20; python $root/tools/time_host_scalars.py 16; echo "# 2^16 points with byte tables:"; python $root/tools/time_host_scalars.py 16 --tables) > $out/${R}_host_scalars.txt 2>/dev/null
