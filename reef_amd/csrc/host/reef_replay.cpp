@@ -263,7 +263,7 @@ int main(int argc, char **argv) {
     bool nofold = false, tables = false;
     for (int i = 2; i < argc; ++i) {
         if (strcmp(argv[i], "nofold") == 0) nofold = true;
-        else if (strcmp(argv[i], "tables") == 0) tables = true;       // a long-lived prover: the keys have earned their byte tables
+        else if (strcmp(argv[i], "tables") == 0) tables = true;       // the keys' byte tables are ready before the first MSM (a real run builds them in the background)
     }
     Curve cv[2];
     cv[0].id = REEF_PALLAS; cv[0].n = next_pow2(sh->w1 > sh->c1 ? sh->w1 : sh->c1);
