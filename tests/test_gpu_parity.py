@@ -698,3 +698,37 @@ def test_byte_tables_are_built_in_the_background_by_default(gpu_lib, cref):
         assert not small.has_byte_tables()
     with msm.MsmContext(cid, bases, bucket_groups=0, byte_tables=1) as plain:               # not pre-shifted: no tables
         assert not plain.has_byte_tables()
+
+
+def test_byte_tables_switch_under_concurrent_callers(gpu_lib, cref):
+    """Four caller threads on clones of one key issue MSMs from the moment the key exists, through the background build and
+    the switch to the byte tables: every result is the same point."""
+    import time
+    from reef_amd import msm
+    cid, n = 1, 30000
+    bases = cref.gen_bases_ap(cid, 314, 15, n)
+    sc = cref.gen_scalars(cid, 27, n)
+    want = cref.compress(cid, cref.msm_pippenger(cid, bases, sc, threads=8))
+    with msm.MsmContext(cid, bases, bucket_groups=1) as ctx:
+        clones = [ctx.clone() for _ in range(4)]
+        bad, calls = [], [0] * 4
+        stop = time.time() + 1.5
+
+        def work(j):
+            while time.time() < stop or not clones[j].has_byte_tables():
+                if msm.compress(cid, clones[j].msm(sc)) != want:
+                    bad.append(j)
+                calls[j] += 1
+                if time.time() > stop + 20:
+                    bad.append(("never ready", j))
+                    break
+            for _ in range(3):                                                 # and a few calls after the switch
+                if msm.compress(cid, clones[j].msm(sc)) != want:
+                    bad.append(("after", j))
+        ts = [threading.Thread(target=work, args=(j,)) for j in range(4)]
+        [t.start() for t in ts]
+        [t.join() for t in ts]
+        assert not bad, bad
+        assert min(calls) > 3 and ctx.has_byte_tables()
+        for c in clones:
+            c.close()
