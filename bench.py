@@ -49,6 +49,7 @@ def parse():
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--cpu-seconds", type=float, default=12.0)
     p.add_argument("--no-check", action="store_true")
+    p.add_argument("--no-replay", action="store_true", help="skip the replay of Reef's own MSM sequence (config.replay_cfg3) after the timed region")
     p.add_argument("--exercise-collective", action="store_true",
                    help="with --gpus 1: run the N > 1 code path (process group of one rank, all_gather + on-device combine) "
                         "to check the RCCL/stream plumbing on a single-GPU box")
@@ -82,38 +83,71 @@ def point_of_dlog(curve_name, k):
 
 
 def cpu_baseline(curve_id, seconds):
-    """Oracle C Pippenger (halo2-style cpu_best_multiexp restatement) on the host cores."""
+    """Oracle C Pippenger on the host cores: the window-parallel form on a persistent thread pool (pasta-msm's shape: one
+    window size for the whole input, Booth digits, (window, point-slice) tiles dealt out to the pool)."""
     from oracle import pasta_ref as R
     cores = os.cpu_count() or 1
     n = 1 << 18
     bases = R.gen_bases_ap(curve_id, 3, 5, n)
     sc = R.gen_scalars(curve_id, 0x5EEF, n)
-    # the restatement deals the points out in chunks, one Pippenger per thread: more threads mean smaller, less efficient
-    # chunks, so the thread count is chosen by a quick probe among all / half / a quarter of the host cores
+    R.msm_pippenger_windows(curve_id, bases, sc, threads=cores)          # creates the pool's threads
     best = None
-    for t in sorted({cores, max(1, cores // 2), max(1, cores // 4)}, reverse=True):
+    for t in sorted({cores, max(1, cores // 2)}, reverse=True):          # SMT siblings may or may not help integer work
         t0 = time.perf_counter()
-        R.msm_pippenger(curve_id, bases, sc, threads=t)
+        R.msm_pippenger_windows(curve_id, bases, sc, threads=t)
         dt = time.perf_counter() - t0
         if best is None or dt < best[1]:
             best = (t, dt)
     threads, dt = best
     rate = n / dt
-    logn = 14
-    while logn < 20 and (1 << (logn + 1)) / rate * 0.6 < seconds:   # larger MSMs are more efficient per pair
+    logn = 18
+    while logn < 20 and (1 << (logn + 1)) / rate * 3 < seconds:          # the bench's own size when the budget allows
         logn += 1
-    n = 1 << logn
-    bases = R.gen_bases_ap(curve_id, 3, 5, n)
-    sc = R.gen_scalars(curve_id, 0x5EEF, n)
+    if logn != 18:
+        n = 1 << logn
+        bases = R.gen_bases_ap(curve_id, 3, 5, n)
+        sc = R.gen_scalars(curve_id, 0x5EEF, n)
     reps, spent = 0, 0.0
-    while spent < seconds * 0.5 or reps == 0:
+    while spent < seconds * 0.5 or reps < 2:
         t0 = time.perf_counter()
-        R.msm_pippenger(curve_id, bases, sc, threads=threads)
+        R.msm_pippenger_windows(curve_id, bases, sc, threads=threads)
         spent += time.perf_counter() - t0
         reps += 1
-    return {"value": n * reps / spent, "unit": "pairs/s", "cores": threads, "kind": "port",
-            "sample": f"{reps} x 2^{logn}-point Pallas MSM, uniform scalars, oracle/pasta_ref.c (cpu_best_multiexp restatement, NOT the "
-                      f"reference binary: Reef is Rust and cannot be built here), {threads} threads on {cores} host cores (best of all / half / a quarter)"}
+    c, slices = R.window_plan(n, threads)
+    value = n * reps / spent
+    return {"value": value, "unit": "pairs/s", "cores": threads, "kind": "port", "per_thread": value / threads,
+            "sample": f"{reps} x 2^{logn}-point Pallas MSM, uniform scalars, oracle/pasta_ref.c window-parallel Pippenger (c = {c}, {slices} point "
+                      f"slices per window, persistent thread pool; a restatement, NOT the reference binary: Reef is Rust and cannot be built here), "
+                      f"{threads} threads on {cores} host cores (best of all / half)"}
+
+
+def replay_leg(cpu_seconds_ok=True):
+    """After the timed region, never `value`: the MSM sequence of one `reef --prove` on BASELINE.json configs[2]
+    (src/backend/framework.rs:664-723) issued in-process through the C ABI by the C++ harness (per-step scalars in host
+    memory, commitments back to the host, every one checked), and the same sequence on the host cores through the oracle."""
+    from reef_amd import replay
+    out = {}
+    g = replay.run("cfg3", nofold=True, tables=False)
+    out.update({"workload": g["replay"], "shapes": "tests/golden/replay_shapes.json (Reef's cost model restated: oracle/costs_oracle.py)",
+                "w1": g["w1"], "c1": g["c1"], "w2": g["w2"], "c2": g["c2"], "steps": g["steps"],
+                "fold_ms_per_step": g["ms_per_step"], "fold_ms_per_step_batched_pairs": g["ms_per_step_batched_pairs"],
+                "ipa_ms": g["ipa_pallas_ms"] + g["ipa_vesta_ms"], "consistency_ipa_ms": g["consistency_ipa_ms"],
+                "total_prove_msm_ms": g["total_prove_msm_ms"], "total_prove_gpu_ms": g["total_prove_gpu_ms"], "setup_ms": g["setup_ms"],
+                "commitments_checked_against_dlog": g["commitments_checked_against_dlog"],
+                "scalars": "host memory in, commitments back to the host (PCIe-inclusive)", "ipa": g["ipa"]})
+    try:
+        t = replay.run("cfg3", nofold=True, tables=True)
+        out["byte_tables"] = {"fold_ms_per_step": t["ms_per_step"], "ipa_ms": t["ipa_pallas_ms"] + t["ipa_vesta_ms"],
+                              "total_prove_msm_ms": t["total_prove_msm_ms"], "setup_ms": t["setup_ms"],
+                              "commitments_checked_against_dlog": t["commitments_checked_against_dlog"]}
+    except Exception as e:
+        out["byte_tables"] = {"error": str(e)}
+    if cpu_seconds_ok:
+        from oracle import replay_cpu
+        c = replay_cpu.run("cfg3", replay.SHAPES_PATH, os.cpu_count() or 1)
+        out.update({"cpu_restatement_ms": c["total_prove_msm_ms"], "cpu_fold_ms_per_step": c["ms_per_step"],
+                    "cpu_ipa_ms": c["ipa_pallas_ms"] + c["ipa_vesta_ms"], "cores": c["threads"], "cpu_kind": c["kind"]})
+    return out
 
 
 def main():
@@ -121,8 +155,8 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != a.gpus and world > 1:
-        a.gpus = world
+    if world > 1 and world != a.gpus:
+        raise SystemExit(f"bench.py: --gpus {a.gpus} but WORLD_SIZE={world}: launch one rank per GPU (torch.distributed.run --nproc-per-node {a.gpus})")
     import numpy as np
     import torch
     import torch.distributed as dist
@@ -149,6 +183,8 @@ def main():
             dist.init_process_group("nccl", device_id=dev)
         else:
             dist.init_process_group("gloo")
+        if dist.get_world_size() != a.gpus:      # the first multi-GPU run must not quietly measure something else
+            raise RuntimeError(f"--gpus {a.gpus} but the process group has {dist.get_world_size()} ranks")
     n = 1 << a.logn
     k0, d = 0xABCDEF, 0x12345
     kind = 0 if a.scalars == "uniform" else 1
@@ -211,6 +247,7 @@ def main():
             print(f"[bench] collective on the MSM stream failed ({e}); ordering by host sync instead", file=sys.stderr)
             for x in exch:
                 x.stream_ctx = None
+    stream_ordered = bool(multi and a.backend == "nccl" and exch and all(x.stream_ctx is not None for x in exch))
     for i in range(a.warmup):
         step(i)
     sync_all()
@@ -239,6 +276,79 @@ def main():
     last = (a.steps - 1) % nctx
     final_parts = parts[last].cpu().numpy().copy()
     final_result = results[last].cpu().numpy().copy()
+
+    # ---- N > 1, after the timed region (never `value`): the two STRONG splits of ONE 2^logn-point MSM on the same ranks ----
+    # (a) by Pippenger window, the split north_star names: every rank holds all points and scalars and accumulates the
+    #     windows w = rank (mod N) (reef_msm_ctx_set_window_split); (b) by points: rank r owns pairs [r n/N, (r+1) n/N).
+    # Both end in the same all-gather of 96-byte partial sums + on-device add; both results are checked below against
+    # the discrete logarithm of the whole MSM.  The weak-scaling region above stays the bench line's `value`.
+    strong = None
+    strong_results = {}
+    if multi and a.gpus > 1 and not by_windows:
+        from reef_amd.distributed import shard_bounds
+        cdev0 = dev if a.backend == "nccl" else "cpu"
+        ksteps = max(3, min(a.steps, 20))
+
+        def make_exch(c):
+            sc_ = None
+            if a.backend == "nccl" and stream_ordered:
+                es_ = torch.cuda.ExternalStream(c.stream, device=dev)
+                sc_ = (lambda e_: (lambda: torch.cuda.stream(e_)))(es_)
+            return PartialSumExchange((lambda c_: (lambda g, cnt, out: c_.sum_points(g.data_ptr(), cnt, out.data_ptr())))(c),
+                                      backend=a.backend, before_exchange=c.sync, stream_ctx=sc_)
+
+        def timed(cs, xs, sc_ptr, cnt):
+            def one(i):
+                j = i % len(cs)
+                cs[j].msm(sc_ptr, cnt, out=parts[j].data_ptr())
+                xs[j].combine(parts[j], gathered[j], results[j])
+            def sync_cs():
+                for c in cs:
+                    c.sync()
+                torch.cuda.synchronize()
+            for i in range(len(cs)):
+                one(i)
+            sync_cs()
+            dist.barrier()
+            torch.cuda.synchronize()
+            t0_ = time.perf_counter()
+            for i in range(ksteps):
+                one(i)
+            sync_cs()
+            dist.barrier()
+            torch.cuda.synchronize()
+            t_ = torch.tensor([time.perf_counter() - t0_], dtype=torch.float64, device=cdev0)
+            dist.all_reduce(t_, op=dist.ReduceOp.MAX)
+            return float(t_.item()) / ksteps * 1e3, results[(ksteps - 1) % len(cs)].cpu().numpy().copy()
+
+        # rank 0's points and scalars are THE MSM; the other ranks generate the same ones (seeded, on the device)
+        bases0 = bases if rank == 0 else msm.gen_bases(a.curve, k0, d, n, device=True)
+        scal0 = scalars if rank == 0 else msm.gen_scalars(a.curve, 0x5EEF, n, kind=kind, mont=True, device=True)
+        if rank == 0:
+            wfirst = ctx0.clone()
+        else:
+            wfirst = msm.MsmContext(a.curve, bases0, n, window_bits=a.window_bits, bucket_groups=groups, chunk=a.chunk)
+        wfirst.set_window_split(rank, world)
+        wctx = [wfirst] + [wfirst.clone() for _ in range(nctx - 1)]          # clones inherit the split
+        w_ms, w_res = timed(wctx, [make_exch(c) for c in wctx], scal0, n)
+        for c in wctx:
+            c.close()
+        lo, hi = shard_bounds(n, world, rank)
+        bases_s = msm.gen_bases(a.curve, k0 + lo * d, d, hi - lo, device=True)
+        pfirst = msm.MsmContext(a.curve, bases_s, hi - lo, window_bits=a.window_bits, bucket_groups=groups, chunk=a.chunk)
+        pctx = [pfirst] + [pfirst.clone() for _ in range(nctx - 1)]
+        p_ms, p_res = timed(pctx, [make_exch(c) for c in pctx], scal0.ptr + 32 * lo, hi - lo)
+        for c in pctx:
+            c.close()
+        one_gpu_ms = elapsed / a.steps * 1e3      # what one GPU needs for a 2^logn-point MSM in the same regime (the weak region above)
+        strong = {"one_msm_points": n, "steps": ksteps, "in_flight": nctx,
+                  "windows_ms_per_step": w_ms, "points_ms_per_step": p_ms,
+                  "speedup_vs_1": {"windows": one_gpu_ms / w_ms, "points": one_gpu_ms / p_ms},
+                  "one_gpu_ms_per_step": one_gpu_ms,
+                  "note": "ONE 2^logn-point MSM split over the ranks (strong scaling), timed after the weak-scaling region with the same barrier + "
+                          "max-over-ranks protocol; windows = reef_msm_ctx_set_window_split(rank, N) on replicated points and scalars, points = "
+                          "contiguous slices; one_gpu_ms_per_step is the weak region's ms_per_step (a 2^logn-point MSM per GPU)"}
+        strong_results = {"windows": w_res, "points": p_res}
 
     # ---- after the timed region (none of this is `value`) ------------------------------------------------
     # (1) the accumulation kernel with ONE MSM in flight: with several MSMs sharing the chip a launch is stretched by
@@ -306,6 +416,11 @@ def main():
                 dist.all_gather(allw, words)
                 total_dlog = sum(sum(int(v) << (32 * j) for j, v in enumerate(w.tolist())) for w in allw)
             ok = ok and got_total == point_of_dlog(a.curve, total_dlog)     # EVERY rank checks the combined point against the expected total
+            if strong_results:                # both strong splits computed rank 0's MSM: its discrete log is the first gathered one
+                dlog0 = sum(int(v) << (32 * j) for j, v in enumerate(allw[0].tolist()))
+                want0 = point_of_dlog(a.curve, dlog0)
+                for name_, res_ in strong_results.items():
+                    ok = ok and msm.compress(a.curve, res_.view(np.uint64)) == want0
             partials_differ = (got_part != got_total) if a.gpus > 1 else None
             flag = torch.tensor([1 if ok else 0, 1 if (partials_differ or a.gpus == 1) else 0], device=cdev)
             dist.all_reduce(flag, op=dist.ReduceOp.MIN)
@@ -347,7 +462,9 @@ def main():
                        "streams": nctx, "sharding": ("windows (w = rank mod N)" if by_windows else "points") if a.gpus > 1 else "none",
                        "exchange": ("none" if a.gpus == 1 else "rccl all_gather of 96 B partials + on-device add" if a.backend == "nccl"
                                     else "HOST-STAGED gloo all_gather of 96 B partials (debug fallback, not RCCL) + on-device add"),
-                       "check": check, "partials_differ_from_total": partials_differ, "msm_ms_stream": tot_ms},
+                       "check": check, "partials_differ_from_total": partials_differ, "msm_ms_stream": tot_ms,
+                       "strong_scaling": strong,
+                       "rccl": ({"ranks_seen": dist.get_world_size(), "backend": a.backend, "stream_ordered": stream_ordered} if multi else None)},
             "roofline": {"bound": "hbm", "kernel": "k_accum0 (bucket accumulation)", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": traffic,
                          "traffic_source": traffic_src,
@@ -365,6 +482,11 @@ def main():
         }
         if a.gpus == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(msm.curve_id(a.curve), a.cpu_seconds)
+        if a.gpus == 1 and not multi and not a.no_replay:
+            try:
+                out["config"]["replay_cfg3"] = replay_leg(cpu_seconds_ok=not a.no_cpu_baseline)
+            except Exception as e:         # a side measurement never takes the bench line down
+                out["config"]["replay_cfg3"] = {"error": str(e)}
         os.write(json_fd, (json.dumps(out) + "\n").encode())
     if multi:
         dist.barrier()

@@ -2,7 +2,8 @@
  * PARITY UNPINNED BY THE REFERENCE (no MSM known-answer vector exists in /root/reference);
  * pinned instead against oracle/pasta_oracle.py (big-int definition) and SURVEY.md 8c anchors.
  *
- * Plain C11 + unsigned __int128, pthreads for the chunk-per-thread Pippenger.
+ * Plain C11 + unsigned __int128, pthreads: a chunk-per-thread Pippenger (halo2's cpu_best_multiexp shape) and a
+ * window-parallel one on a persistent thread pool (pasta-msm's shape; the timed cpu_baseline).
  */
 #include "pasta_ref.h"
 
@@ -392,6 +393,191 @@ void pasta_ref_msm_pippenger(int curve, const u64 *bases, const u64 *scalars, si
     free(canon);
 }
 
+/* ---------------------------------------------------------------- thread pool ----
+ * A persistent pool (workers are created once and parked on a condition variable), so that a mid-size MSM is not
+ * billed the creation of a few hundred threads: pasta-msm keeps a pool of its own.  Units of one job are handed out
+ * through an atomic counter; the calling thread works too. */
+typedef void (*unit_fn)(void *ctx, size_t unit);
+static struct {
+    pthread_mutex_t mu;
+    pthread_cond_t go, done;
+    pthread_t *tids;
+    int nworkers;          /* threads parked in the pool */
+    unsigned long gen;     /* job generation */
+    int want;              /* workers that may join the current job */
+    int active;            /* workers still inside the current job */
+    unit_fn fn;
+    void *ctx;
+    size_t units;
+    size_t next;           /* next unit to hand out (atomic) */
+} POOL = {PTHREAD_MUTEX_INITIALIZER, PTHREAD_COND_INITIALIZER, PTHREAD_COND_INITIALIZER, NULL, 0, 0, 0, 0, NULL, NULL, 0, 0};
+static pthread_mutex_t POOL_JOB = PTHREAD_MUTEX_INITIALIZER;   /* one job at a time */
+
+static void pool_drain(void) {
+    for (;;) {
+        size_t u = __atomic_fetch_add(&POOL.next, 1, __ATOMIC_RELAXED);
+        if (u >= POOL.units) break;
+        POOL.fn(POOL.ctx, u);
+    }
+}
+static void *pool_worker(void *arg) {
+    const int id = (int)(size_t)arg;
+    unsigned long seen = 0;
+    pthread_mutex_lock(&POOL.mu);
+    for (;;) {
+        while (POOL.gen == seen) pthread_cond_wait(&POOL.go, &POOL.mu);
+        seen = POOL.gen;
+        if (id >= POOL.want) continue;
+        pthread_mutex_unlock(&POOL.mu);
+        pool_drain();
+        pthread_mutex_lock(&POOL.mu);
+        if (--POOL.active == 0) pthread_cond_signal(&POOL.done);
+    }
+    return NULL;
+}
+static void pool_run(int threads, size_t units, unit_fn fn, void *ctx) {
+    if (units == 0) return;
+    if (threads <= 1 || units == 1) {
+        for (size_t u = 0; u < units; ++u) fn(ctx, u);
+        return;
+    }
+    pthread_mutex_lock(&POOL_JOB);
+    const int helpers = threads - 1;
+    pthread_mutex_lock(&POOL.mu);
+    if (POOL.nworkers < helpers) {
+        POOL.tids = (pthread_t *)realloc(POOL.tids, (size_t)helpers * sizeof(pthread_t));
+        pthread_attr_t at;
+        pthread_attr_init(&at);
+        pthread_attr_setdetachstate(&at, PTHREAD_CREATE_DETACHED);
+        while (POOL.nworkers < helpers) {
+            if (pthread_create(&POOL.tids[POOL.nworkers], &at, pool_worker, (void *)(size_t)POOL.nworkers) != 0) break;
+            ++POOL.nworkers;
+        }
+        pthread_attr_destroy(&at);
+    }
+    POOL.fn = fn; POOL.ctx = ctx; POOL.units = units;
+    __atomic_store_n(&POOL.next, 0, __ATOMIC_RELAXED);
+    POOL.want = helpers < POOL.nworkers ? helpers : POOL.nworkers;
+    POOL.active = POOL.want;
+    ++POOL.gen;
+    pthread_cond_broadcast(&POOL.go);
+    pthread_mutex_unlock(&POOL.mu);
+    pool_drain();
+    pthread_mutex_lock(&POOL.mu);
+    while (POOL.active) pthread_cond_wait(&POOL.done, &POOL.mu);
+    pthread_mutex_unlock(&POOL.mu);
+    pthread_mutex_unlock(&POOL_JOB);
+}
+
+/* ------------------------------------------------- window-parallel Pippenger ----
+ * The shape of pasta-msm's own CPU path [recalled, the crate is not in /root/reference]: ONE window size for the whole
+ * input, Booth-recoded signed digits (2^(c-1) buckets per window), the (window, slice of the points) tiles dealt out to
+ * a thread pool, running-sum bucket reduction per tile, Horner over the windows at the end.  Unlike the chunk-per-thread
+ * form above, the window does not shrink with the thread count, which is what made that form a poor baseline. */
+typedef struct {
+    int curve;
+    const aff *bases;
+    const u64 *canon;
+    size_t n;
+    unsigned c, W, S;
+    jac *tile;     /* W * S tile sums */
+} wmsm_job;
+
+static inline int booth_digit(const u64 *k, unsigned w, unsigned c) {
+    /* c + 1 bits starting at bit w*c - 1 (bit -1 is zero): d = b_{-1} + sum_{j < c-1} b_j 2^j - b_{c-1} 2^(c-1) */
+    const unsigned start = w * c;
+    u64 v;
+    if (start == 0) {
+        v = (k[0] << 1) & (((u64)1 << (c + 1)) - 1);
+    } else {
+        const unsigned pos = start - 1, limb = pos >> 6, off = pos & 63;
+        v = limb < 4 ? k[limb] >> off : 0;
+        if (off + c + 1 > 64 && limb + 1 < 4) v |= k[limb + 1] << (64 - off);
+        v &= ((u64)1 << (c + 1)) - 1;
+    }
+    const int lo = (int)(v & 1) + (int)((v >> 1) & (((u64)1 << (c - 1)) - 1));
+    return lo - (int)(((v >> c) & 1) << (c - 1));
+}
+
+static void wmsm_unit(void *ctx, size_t unit) {
+    wmsm_job *j = (wmsm_job *)ctx;
+    const field_t *F = coord_field(j->curve);
+    const unsigned w = (unsigned)(unit / j->S), s = (unsigned)(unit % j->S);
+    const size_t lo = j->n * s / j->S, hi = j->n * (s + 1) / j->S;
+    const size_t nb = (size_t)1 << (j->c - 1);
+    jac *buckets = (jac *)malloc(nb * sizeof(jac));
+    unsigned char *used = (unsigned char *)calloc(nb, 1);
+    for (size_t i = lo; i < hi; ++i) {
+        const int d = booth_digit(j->canon + 4 * i, w, j->c);
+        if (d == 0 || aff_is_inf(&j->bases[i])) continue;
+        const size_t b = (size_t)(d < 0 ? -d : d) - 1;
+        aff p = j->bases[i];
+        if (d < 0) fe_neg(F, &p.y, &p.y);
+        if (!used[b]) { jac_set_inf(F, &buckets[b]); used[b] = 1; }
+        jac_add_affine(F, &buckets[b], &buckets[b], &p);
+    }
+    jac run, acc;
+    jac_set_inf(F, &run);
+    jac_set_inf(F, &acc);
+    for (size_t b = nb; b-- > 0;) {
+        if (used[b]) jac_add(F, &run, &run, &buckets[b]);
+        jac_add(F, &acc, &acc, &run);
+    }
+    j->tile[unit] = acc;
+    free(buckets);
+    free(used);
+}
+
+typedef struct { int curve; const u64 *in; int is_mont; u64 *out; size_t n; size_t per; } canon_job;
+static void canon_unit(void *ctx, size_t unit) {
+    canon_job *j = (canon_job *)ctx;
+    const size_t lo = unit * j->per, hi = lo + j->per > j->n ? j->n : lo + j->per;
+    for (size_t i = lo; i < hi; ++i) scalar_canon(j->curve, j->in + 4 * i, j->is_mont, j->out + 4 * i);
+}
+
+unsigned pasta_ref_window_plan(size_t n, int threads, unsigned *slices_out) {
+    /* cost of the slowest thread in bucket additions: rounds of tiles, each n/S point additions + 2 * 2^(c-1) reduction */
+    unsigned best_c = 2, best_s = 1;
+    double best = 1e300;
+    if (threads < 1) threads = 1;
+    for (unsigned c = 2; c <= 20; ++c) {
+        const unsigned W = (256 + c - 1) / c;
+        for (unsigned S = 1; S <= (unsigned)threads; S = S < 4 ? S + 1 : S + S / 4) {
+            const double units = (double)W * S, rounds = ceil(units / threads);
+            const double cost = rounds * ((double)n / S + 2.0 * (double)((size_t)1 << (c - 1)));
+            if (cost < best) { best = cost; best_c = c; best_s = S; }
+        }
+    }
+    if (slices_out) *slices_out = best_s;
+    return best_c;
+}
+
+void pasta_ref_msm_pippenger_windows(int curve, const u64 *bases, const u64 *scalars, size_t n, int is_mont, int threads,
+                                     u64 *out) {
+    const field_t *F = coord_field(curve);
+    if (threads < 1) threads = 1;
+    jac res;
+    jac_set_inf(F, &res);
+    if (n == 0) { memcpy(out, &res, 96); return; }
+    u64 *canon = (u64 *)malloc(32 * n);
+    canon_job cj = {curve, scalars, is_mont, canon, n, 4096};
+    pool_run(threads, (n + cj.per - 1) / cj.per, canon_unit, &cj);
+    wmsm_job j;
+    j.curve = curve; j.bases = (const aff *)bases; j.canon = canon; j.n = n;
+    j.c = pasta_ref_window_plan(n, threads, &j.S);
+    if (j.S > n) j.S = (unsigned)n;
+    j.W = (256 + j.c - 1) / j.c;
+    j.tile = (jac *)malloc((size_t)j.W * j.S * sizeof(jac));
+    pool_run(threads, (size_t)j.W * j.S, wmsm_unit, &j);
+    for (int w = (int)j.W - 1; w >= 0; --w) {
+        for (unsigned k = 0; k < j.c; ++k) jac_dbl(F, &res, &res);
+        for (unsigned s = 0; s < j.S; ++s) jac_add(F, &res, &res, &j.tile[(size_t)w * j.S + s]);
+    }
+    memcpy(out, &res, 96);
+    free(j.tile);
+    free(canon);
+}
+
 void pasta_ref_to_affine(int curve, const u64 *jacs, size_t n, u64 *out) {
     const field_t *F = coord_field(curve);
     for (size_t i = 0; i < n; ++i) jac_to_aff(F, (aff *)(out + 8 * i), (const jac *)(jacs + 12 * i));
@@ -518,6 +704,30 @@ void pasta_ref_fold(int curve, const u64 *gens, size_t half, const u64 *w1, cons
         jac_add(F, &a, &a, &b);
         jac_to_aff(F, (aff *)(out + 8 * i), &a);
     }
+}
+
+typedef struct { int curve; const aff *L, *R; size_t half; const u64 *w1, *w2; u64 *out; size_t per; } fold_job;
+static void fold_unit(void *ctx, size_t unit) {
+    fold_job *j = (fold_job *)ctx;
+    const field_t *F = coord_field(j->curve);
+    const size_t lo = unit * j->per, hi = lo + j->per > j->half ? j->half : lo + j->per;
+    for (size_t i = lo; i < hi; ++i) {
+        /* one joint double-and-add chain per pair: what nova's 2-term vartime_multiscalar_mul (cpu_best_multiexp with
+         * c = 1 for n < 4 [recalled]) amounts to -- 256 doublings shared by both scalars */
+        jac a;
+        jac_set_inf(F, &a);
+        for (int bit = 255; bit >= 0; --bit) {
+            jac_dbl(F, &a, &a);
+            if ((j->w1[bit >> 6] >> (bit & 63)) & 1) jac_add_affine(F, &a, &a, &j->L[i]);
+            if ((j->w2[bit >> 6] >> (bit & 63)) & 1) jac_add_affine(F, &a, &a, &j->R[i]);
+        }
+        jac_to_aff(F, (aff *)(j->out + 8 * i), &a);
+    }
+}
+/* the same fold dealt out to the thread pool (nova folds its generators with rayon) */
+void pasta_ref_fold_mt(int curve, const u64 *gens, size_t half, const u64 *w1, const u64 *w2, int threads, u64 *out) {
+    fold_job j = {curve, (const aff *)gens, (const aff *)gens + half, half, w1, w2, out, 8};
+    pool_run(threads, (half + j.per - 1) / j.per, fold_unit, &j);
 }
 
 typedef struct {

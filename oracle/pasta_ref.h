@@ -34,6 +34,13 @@ void pasta_ref_msm_naive(int curve, const uint64_t *bases_affine, const uint64_t
 void pasta_ref_msm_pippenger(int curve, const uint64_t *bases_affine, const uint64_t *scalars,
                              size_t n, int scalars_are_mont, int threads, uint64_t *out_jacobian);
 
+/* Window-parallel bucket method on a persistent thread pool -- the shape of pasta-msm's own CPU path [recalled]: one
+ * window size for the whole input (pasta_ref_window_plan), Booth-recoded signed digits, (window, point-slice) tiles dealt
+ * out to the pool, running-sum reduction per tile, Horner over the windows.  This is the timed cpu_baseline of bench.py. */
+void pasta_ref_msm_pippenger_windows(int curve, const uint64_t *bases_affine, const uint64_t *scalars,
+                                     size_t n, int scalars_are_mont, int threads, uint64_t *out_jacobian);
+unsigned pasta_ref_window_plan(size_t n, int threads, unsigned *slices_out);
+
 /* Jacobian (96 B) -> affine (64 B, Montgomery; identity -> (0,0)) and 32-byte compressed form
  * (LE canonical x, y parity in bit 255; identity = zeros). */
 void pasta_ref_to_affine(int curve, const uint64_t *jac, size_t n, uint64_t *out_affine);
@@ -66,6 +73,9 @@ void pasta_ref_from_mont(int field, const uint64_t *a, uint64_t *out);
  * i < half, L = gens[0..half], R = gens[half..2*half]; w canonical; output affine Montgomery. */
 void pasta_ref_fold(int curve, const uint64_t *gens_affine, size_t half, const uint64_t *w1,
                     const uint64_t *w2, uint64_t *out_affine);
+
+void pasta_ref_fold_mt(int curve, const uint64_t *gens_affine, size_t half, const uint64_t *w1,
+                       const uint64_t *w2, int threads, uint64_t *out_affine);
 
 /* Hyrax-style row commitments (restates HyraxPC::commit, src/backend/commitment.rs:187):
  * out_r = sum_j Z[r*row_len + j]*G_j (+ blinds[r]*H if blinds != NULL). Jacobian out. */

@@ -35,6 +35,10 @@ def lib() -> ctypes.CDLL:
         vp, sz, i32, u64 = ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_uint64
         _lib.pasta_ref_msm_naive.argtypes = [i32, vp, vp, sz, i32, vp]
         _lib.pasta_ref_msm_pippenger.argtypes = [i32, vp, vp, sz, i32, i32, vp]
+        _lib.pasta_ref_msm_pippenger_windows.argtypes = [i32, vp, vp, sz, i32, i32, vp]
+        _lib.pasta_ref_window_plan.argtypes = [sz, i32, ctypes.POINTER(ctypes.c_uint)]
+        _lib.pasta_ref_window_plan.restype = ctypes.c_uint
+        _lib.pasta_ref_fold_mt.argtypes = [i32, vp, sz, vp, vp, i32, vp]
         _lib.pasta_ref_to_affine.argtypes = [i32, vp, sz, vp]
         _lib.pasta_ref_compress.argtypes = [i32, vp, sz, vp]
         _lib.pasta_ref_scalar_mul.argtypes = [i32, vp, vp, vp]
@@ -81,6 +85,19 @@ def msm_pippenger(curve: int, bases: np.ndarray, scalars: np.ndarray, mont: bool
     return out
 
 
+def msm_pippenger_windows(curve: int, bases: np.ndarray, scalars: np.ndarray, mont: bool = True, threads: int = 1, n: int | None = None) -> np.ndarray:
+    """Window-parallel Pippenger on the persistent thread pool (the timed cpu_baseline); n: prefix length."""
+    out = np.zeros(12, dtype=np.uint64)
+    lib().pasta_ref_msm_pippenger_windows(curve, _p(bases), _p(scalars), bases.shape[0] if n is None else n, int(mont), threads, _p(out))
+    return out
+
+
+def window_plan(n: int, threads: int) -> tuple[int, int]:
+    s = ctypes.c_uint(0)
+    c = lib().pasta_ref_window_plan(n, threads, ctypes.byref(s))
+    return int(c), int(s.value)
+
+
 def to_affine(curve: int, jac: np.ndarray) -> np.ndarray:
     jac = np.ascontiguousarray(jac.reshape(-1, 12))
     out = np.zeros((jac.shape[0], 8), dtype=np.uint64)
@@ -108,6 +125,14 @@ def fold(curve: int, gens: np.ndarray, w1: int, w2: int) -> np.ndarray:
     b = np.array([(w2 >> (64 * i)) & 0xFFFFFFFFFFFFFFFF for i in range(4)], dtype=np.uint64)
     out = np.zeros((half, 8), dtype=np.uint64)
     lib().pasta_ref_fold(curve, _p(gens), half, _p(a), _p(b), _p(out))
+    return out
+
+
+def fold_mt(curve: int, gens: np.ndarray, w1: int, w2: int, threads: int, half: int | None = None) -> np.ndarray:
+    half = gens.shape[0] // 2 if half is None else half
+    a, b = int_to_limbs(w1), int_to_limbs(w2)
+    out = np.zeros((half, 8), dtype=np.uint64)
+    lib().pasta_ref_fold_mt(curve, _p(gens), half, _p(a), _p(b), threads, _p(out))
     return out
 
 

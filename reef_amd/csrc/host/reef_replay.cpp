@@ -21,22 +21,30 @@
 // arithmetic progression B_i = (k0 + i*d)*G, so each MSM has a known discrete logarithm; every per-step
 // commitment is compared with (sum_i s_i*(k0 + i*d) mod r)*G computed from host big-integer arithmetic and a
 // one-point key, and the replay aborts on the first mismatch.  The sizes are PREDICTIONS of Reef's cost model
-// (src/backend/costs.rs restated in SURVEY.md 8), not measurements of a Reef run: flagged in the JSON line.
-// Build: g++ -O2 -std=c++17 reef_replay.cpp -I../../../include -L../../_lib -lreef_msm -o reef_replay
+// (src/backend/costs.rs), not measurements of a Reef run: flagged in the JSON line.  No MSM length is typed in here: the
+// shapes are read from tests/golden/replay_shapes.json, which oracle/gen_replay_shapes.py derives from its restatement of
+// costs.rs (the SAFA shape of each regex is an input of that script).
+//
+// One translation unit, two artefacts (csrc/Makefile): libreef_replay.so exports reef_replay_run() -- bench.py calls it
+// in-process after its timed region, tests/test_gpu_replay.py under pytest -- and the reef_replay executable is its main().
+// Build: g++ -O2 -std=c++17 -fPIC -shared reef_replay.cpp -I../../../include -L../../_lib -lreef_msm -o libreef_replay.so
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <stdexcept>
 #include <string>
 #include <vector>
 
 #include "reef_msm.h"
 #include "replay_standins.h"
 
+// a failed call ends the replay with its message (reef_replay_run returns it; the executable prints it and exits non-zero)
+[[noreturn]] static void fail(const std::string &msg) { throw std::runtime_error(msg); }
 #define CK(x)                                                                              \
     do {                                                                                   \
         reef_status s_ = (x);                                                              \
-        if (s_ != REEF_OK) { fprintf(stderr, "%s failed: %s\n", #x, reef_last_error()); exit(1); } \
+        if (s_ != REEF_OK) fail(std::string(#x) + " failed: " + reef_last_error());        \
     } while (0)
 
 using clk = std::chrono::steady_clock;
@@ -92,23 +100,66 @@ static reef_fe dlog_of_msm(int curve, const reef_fe *canon, size_t n, uint64_t k
 }
 
 struct Shape {
-    const char *name;
-    size_t w1, c1, w2, c2;   // |W1|, |C1| (Pallas), |W2|, |C2| (Vesta)
-    int steps;
-    size_t hyrax_row;        // R = 2^(l - l/2): length of the consistency IPA (0 = merkle mode)
-    int doc_log;             // l = log2 of the padded document length the Hyrax commitment covers (0: no Hyrax commitment)
-    int symbol_bits;         // width of a document symbol (alphabet + EOF/EPSILON, framework.rs:978-1011)
-    int table_log;           // log2 of the table the per-step nlookup sum-check runs over (r1cs.rs:2318-2385); 0: not replayed
-    int lookups;             // lookups folded per step (batch size)
-    int merkle_log;          // --merkle: log2 of the document the Poseidon tree commits to (0: Hyrax commitment)
+    std::string name;
+    size_t w1 = 0, c1 = 0, w2 = 0, c2 = 0;   // |W1|, |C1| (Pallas), |W2|, |C2| (Vesta)
+    int steps = 0;
+    size_t hyrax_row = 0;    // R = 2^(l - l/2): length of the consistency IPA (0 = merkle mode)
+    int doc_log = 0;         // l = log2 of the padded document length the Hyrax commitment covers (0: no Hyrax commitment)
+    int symbol_bits = 0;     // width of a document symbol (alphabet + EOF/EPSILON, framework.rs:978-1011)
+    int table_log = 0;       // log2 of the table the per-step nlookup sum-check runs over (r1cs.rs:2318-2385); 0: not replayed
+    int lookups = 0;         // lookups folded per step (batch size)
+    int merkle_log = 0;      // --merkle: log2 of the document the Poseidon tree commits to (0: Hyrax commitment)
 };
-// BASELINE.json configs as sized in SURVEY.md 8 (predictions of costs.rs, not measurements)
-static const Shape SHAPES[] = {
-    {"cfg1_9B_ascii", 17000, 16700, 11400, 11376, 3, 4, 4, 8, 10, 4, 0},
-    {"cfg3_1MiB_ascii_password", 26000, 26000, 11400, 11376, 3, 2048, 21, 8, 21, 16, 0},
-    {"cfg4_16MiB_dna_hybrid_b32", 39000, 39000, 11400, 11376, 4, 8192, 25, 3, 26, 32, 0},
-    {"cfg5_64MiB_utf8_merkle", 65000, 65000, 11400, 11376, 4, 0, 0, 8, 0, 32, 26},
-};
+
+// ---- tests/golden/replay_shapes.json: the "shapes" array of flat objects written by oracle/gen_replay_shapes.py ----
+static std::string read_file(const std::string &path) {
+    FILE *f = fopen(path.c_str(), "rb");
+    if (!f) fail("cannot open the replay shapes file " + path + " (generated by oracle/gen_replay_shapes.py)");
+    std::string s;
+    char buf[4096];
+    size_t got;
+    while ((got = fread(buf, 1, sizeof buf, f)) > 0) s.append(buf, got);
+    fclose(f);
+    return s;
+}
+static long long json_int(const std::string &obj, const char *key) {
+    const std::string k = std::string("\"") + key + "\":";
+    size_t p = obj.find(k);
+    if (p == std::string::npos) fail(std::string("replay shapes: field ") + key + " missing");
+    return atoll(obj.c_str() + p + k.size());
+}
+static Shape load_shape(const std::string &path, const char *which) {
+    const std::string text = read_file(path);
+    size_t p = text.find("\"shapes\":");
+    if (p == std::string::npos) fail("replay shapes: no \"shapes\" array in " + path);
+    for (;;) {
+        const size_t b = text.find('{', p);
+        if (b == std::string::npos) break;
+        const size_t e = text.find('}', b);
+        if (e == std::string::npos) break;
+        const std::string obj = text.substr(b, e - b + 1);
+        p = e + 1;
+        const size_t np = obj.find("\"name\":");
+        if (np == std::string::npos) continue;
+        const size_t q0 = obj.find('"', np + 7), q1 = obj.find('"', q0 + 1);
+        const std::string name = obj.substr(q0 + 1, q1 - q0 - 1);
+        if (name.find(which) == std::string::npos) continue;
+        Shape s;
+        s.name = name;
+        s.w1 = (size_t)json_int(obj, "w1"); s.c1 = (size_t)json_int(obj, "c1");
+        s.w2 = (size_t)json_int(obj, "w2"); s.c2 = (size_t)json_int(obj, "c2");
+        s.steps = (int)json_int(obj, "steps");
+        s.hyrax_row = (size_t)json_int(obj, "hyrax_row");
+        s.doc_log = (int)json_int(obj, "doc_log");
+        s.symbol_bits = (int)json_int(obj, "symbol_bits");
+        s.table_log = (int)json_int(obj, "table_log");
+        s.lookups = (int)json_int(obj, "lookups");
+        s.merkle_log = (int)json_int(obj, "merkle_log");
+        if (!s.w1 || !s.c1 || !s.w2 || !s.c2 || s.steps < 1) fail("replay shapes: " + name + " is not a usable shape");
+        return s;
+    }
+    fail(std::string("replay shapes: no config matching '") + which + "' in " + path);
+}
 
 struct Curve {
     int id;
@@ -127,10 +178,8 @@ static void check_point(Curve &c, const reef_jacobian &got, const reef_fe &dlog,
     reef_jacobian both[2] = {got, want};
     reef_affine aff[2];
     CK(reef_normalize(c.id, both, 2, REEF_HOST, aff, nullptr));
-    if (memcmp(&aff[0], &aff[1], sizeof(reef_affine)) != 0) {
-        fprintf(stderr, "reef_replay: %s on curve %d differs from its discrete-logarithm closed form\n", what, c.id);
-        exit(4);
-    }
+    if (memcmp(&aff[0], &aff[1], sizeof(reef_affine)) != 0)
+        fail(std::string("reef_replay: ") + what + " on curve " + std::to_string(c.id) + " differs from its discrete-logarithm closed form");
     ++g_checked;
 }
 
@@ -138,7 +187,7 @@ static size_t next_pow2(size_t x) { size_t p = 1; while (p < x) p <<= 1; return 
 
 static reef_fe *device_scalars(int curve, uint64_t seed, int kind, size_t n) {
     reef_fe *p = (reef_fe *)reef_device_alloc(n * sizeof(reef_fe));
-    if (!p) { fprintf(stderr, "alloc: %s\n", reef_last_error()); exit(1); }
+    if (!p) fail(std::string("alloc: ") + reef_last_error());
     CK(reef_gen_scalars(curve, seed, kind, 0, n, true, p, REEF_DEVICE));
     return p;
 }
@@ -204,7 +253,7 @@ static uint8_t *device_symbols(size_t n, int bits, uint64_t seed) {
         h[i] = (uint8_t)((x >> 33) % bound);
     }
     uint8_t *d = (uint8_t *)reef_device_alloc(n);
-    if (!d) { fprintf(stderr, "alloc: %s\n", reef_last_error()); exit(1); }
+    if (!d) fail(std::string("alloc: ") + reef_last_error());
     CK(reef_memcpy(d, h.data(), n, REEF_DEVICE, REEF_HOST));
     return d;
 }
@@ -249,22 +298,9 @@ static double run_sumcheck_step(reef_sc_ctx *sc, int ell, int lookups) {
     return ms_since(t0);
 }
 
-int main(int argc, char **argv) {
-    const char *which = argc > 1 ? argv[1] : "cfg3_1MiB_ascii_password";
-    const Shape *sh = nullptr;
-    for (const Shape &s : SHAPES)
-        if (strstr(s.name, which)) sh = &s;
-    if (!sh) {
-        fprintf(stderr, "usage: reef_replay [cfg1|cfg3|cfg4|cfg5] [nofold] [tables]\n");
-        return 2;
-    }
-    if (reef_device_count() < 1) { fprintf(stderr, "no GPU: %s\n", reef_last_error()); return 3; }
-
-    bool nofold = false, tables = false;
-    for (int i = 2; i < argc; ++i) {
-        if (strcmp(argv[i], "nofold") == 0) nofold = true;
-        else if (strcmp(argv[i], "tables") == 0) tables = true;       // the keys' byte tables are ready before the first MSM (a real run builds them in the background)
-    }
+// The whole replay of one config; returns the JSON line.
+static std::string replay_body(const Shape &shape, bool nofold, bool tables, const std::string &shapes_path) {
+    const Shape *sh = &shape;
     Curve cv[2];
     cv[0].id = REEF_PALLAS; cv[0].n = next_pow2(sh->w1 > sh->c1 ? sh->w1 : sh->c1);
     cv[1].id = REEF_VESTA;  cv[1].n = next_pow2(sh->w2 > sh->c2 ? sh->w2 : sh->c2);
@@ -329,9 +365,11 @@ int main(int argc, char **argv) {
     msm(cv[0], hW1, sh->w1); check_point(cv[0], out, eW1, "comm_W1");
     msm(cv[1], hW2, sh->w2); check_point(cv[1], out, eW2, "comm_W2");
 
-    auto t_steps = clk::now();
+    // a config may fold in a single step: time at least three so that the per-step figure is not one sample; the totals
+    // below charge the config's own number of steps
+    const int timed_steps = sh->steps < 3 ? 3 : sh->steps;
     std::vector<double> step_ms;
-    for (int i = 0; i < sh->steps; ++i) {
+    for (int i = 0; i < timed_steps; ++i) {
         auto ts = clk::now();
         reef_jacobian o[4];
         msm(cv[1], hT2, sh->c2); o[0] = out;
@@ -346,7 +384,7 @@ int main(int argc, char **argv) {
     }
     double steps_ms = 0;
     for (double v : step_ms) steps_ms += v;
-    (void)t_steps;
+    steps_ms = steps_ms / timed_steps * sh->steps;
 
     // The same commitments with the two of each curve issued as ONE batched call (comm_W and comm_T of a
     // step are both absorbed before the folding challenge is drawn, so neither needs the other): rows = 2
@@ -374,8 +412,8 @@ int main(int argc, char **argv) {
             check_point(*pairs[k].c, two[1], expect[k][1], "batched comm_T");
         }
         auto tb = clk::now();
-        for (int i = 0; i < sh->steps; ++i) { both(1); both(0); }
-        steps_batched_ms = ms_since(tb);
+        for (int i = 0; i < timed_steps; ++i) { both(1); both(0); }
+        steps_batched_ms = ms_since(tb) / timed_steps * sh->steps;
     }
 
     auto t_final = clk::now();
@@ -471,16 +509,17 @@ int main(int argc, char **argv) {
     }
 
     const size_t pairs_step = sh->c2 + sh->w1 + sh->c1 + sh->w2;
-    printf("{\"replay\": \"%s\", \"ipa\": \"%s\", \"note\": \"MSM work of reef --prove replayed through the C ABI; host-side proving work not included\", "
-           "\"shapes\": \"PREDICTED by Reef's cost model (src/backend/costs.rs as restated in SURVEY.md 8), not measured on a Reef run\", "
+    std::vector<char> line(8192);
+    snprintf(line.data(), line.size(), "{\"replay\": \"%s\", \"ipa\": \"%s\", \"note\": \"MSM work of reef --prove replayed through the C ABI; host-side proving work not included\", "
+           "\"shapes\": \"PREDICTED by Reef's cost model (src/backend/costs.rs restated in oracle/costs_oracle.py, read from %s), not measured on a Reef run\", \"w1\": %zu, \"c1\": %zu, \"w2\": %zu, \"c2\": %zu, "
            "\"scalars\": \"per-step vectors in host memory, commitments returned to the host (PCIe inclusive)\", \"commitments_checked_against_dlog\": %d, "
            "\"key_pallas\": %zu, \"key_vesta\": %zu, \"steps\": %d, \"setup_ms\": %.3f, \"fold_steps_ms\": %.3f, \"ms_per_step\": %.3f, "
            "\"ms_per_step_batched_pairs\": %.3f, \"pairs_per_step\": %zu, \"final_snark_ms\": %.3f, \"ipa_pallas_ms\": %.3f, \"ipa_pallas_rounds\": %d, \"ipa_vesta_ms\": %.3f, "
            "\"ipa_vesta_rounds\": %d, \"consistency_ipa_ms\": %.3f, \"consistency_rounds\": %d, \"total_prove_msm_ms\": %.3f, "
            "\"commit_hyrax_ms\": %.3f, \"commit_hyrax_first_call_ms\": %.3f, \"sumcheck_table_log\": %d, \"sumcheck_ms_per_step\": %.3f, "
            "\"doc_poly_bind_rows_ms\": %.3f, \"total_prove_gpu_ms\": %.3f, \"derive_both_keys_ms\": %.3f, \"commit_merkle_log\": %d, \"commit_merkle_ms\": %.3f, "
-           "\"standins\": \"key derivation and Poseidon run on stand-in parameter sets (replay_standins.h), timing only\", \"byte_tables\": %s}\n",
-           sh->name, nofold ? "cross terms over the original key (no generator fold)" : "generator fold per round", g_checked, cv[0].n, cv[1].n, sh->steps, setup_ms, steps_ms, steps_ms / sh->steps, steps_batched_ms / sh->steps, pairs_step, final_ms, ipa1_ms, r1, ipa2_ms, r2,
+           "\"standins\": \"key derivation and Poseidon run on stand-in parameter sets (replay_standins.h), timing only\", \"byte_tables\": %s}",
+           sh->name.c_str(), nofold ? "cross terms over the original key (no generator fold)" : "generator fold per round", shapes_path.c_str(), sh->w1, sh->c1, sh->w2, sh->c2, g_checked, cv[0].n, cv[1].n, sh->steps, setup_ms, steps_ms, steps_ms / sh->steps, steps_batched_ms / sh->steps, pairs_step, final_ms, ipa1_ms, r1, ipa2_ms, r2,
            cons_ms, r3, steps_ms + final_ms + cons_ms, commit_ms, commit_first_ms, sh->table_log, sc_step_ms, mle_ms,
            steps_ms + final_ms + cons_ms + sh->steps * sc_step_ms + mle_ms, derive_ms, sh->merkle_log, merkle_ms,
            tables ? "\"built with the keys (inside setup_ms): MSMs of 1025..65536 points are sums of table entries\"" : "\"none (bucket pipeline)\"");
@@ -491,5 +530,56 @@ int main(int argc, char **argv) {
         reef_device_free(c.d_gens);
     }
     reef_device_free(sW1); reef_device_free(sT1); reef_device_free(sW2); reef_device_free(sT2);
-    return 0;
+    return std::string(line.data());
 }
+
+// ---- entry points ---------------------------------------------------------------------------------------------------
+// Runs the replay of the config whose name contains `config` ("cfg1" | "cfg3" | "cfg4" | "cfg5") with the shapes of
+// `shapes_json` (NULL: $REEF_REPLAY_SHAPES).  On success returns 0 and writes the JSON line (NUL-terminated) to out; on
+// failure returns non-zero and writes the message.  Every per-step commitment has been checked by then.
+extern "C" __attribute__((visibility("default")))
+int reef_replay_run(const char *shapes_json, const char *config, int nofold, int tables, char *out, size_t cap) {
+    auto put = [&](const std::string &m) { if (out && cap) { snprintf(out, cap, "%s", m.c_str()); } };
+    try {
+        const char *path = shapes_json && *shapes_json ? shapes_json : getenv("REEF_REPLAY_SHAPES");
+        if (!path) fail("no replay shapes file given (argument or REEF_REPLAY_SHAPES)");
+        if (reef_device_count() < 1) { put(std::string("no GPU: ") + reef_last_error()); return 3; }
+        const Shape sh = load_shape(path, config && *config ? config : "cfg3");
+        g_checked = 0;
+        put(replay_body(sh, nofold != 0, tables != 0, path));
+        return 0;
+    } catch (const std::exception &e) {
+        put(e.what());
+        return 1;
+    }
+}
+
+#if !defined(REEF_REPLAY_NO_MAIN)
+#include <unistd.h>
+int main(int argc, char **argv) {
+    const char *which = argc > 1 ? argv[1] : "cfg3";
+    bool nofold = false, tables = false;
+    std::string shapes;
+    for (int i = 2; i < argc; ++i) {
+        if (strcmp(argv[i], "nofold") == 0) nofold = true;
+        else if (strcmp(argv[i], "tables") == 0) tables = true;       // the keys' byte tables are ready before the first MSM (a real run builds them in the background)
+        else if (strncmp(argv[i], "shapes=", 7) == 0) shapes = argv[i] + 7;
+        else { fprintf(stderr, "usage: reef_replay [cfg1|cfg3|cfg4|cfg5] [nofold] [tables] [shapes=<replay_shapes.json>]\n"); return 2; }
+    }
+    if (shapes.empty() && !getenv("REEF_REPLAY_SHAPES")) {   // the executable lives in reef_amd/_lib/: the shapes are two levels up, under tests/golden/
+        char exe[4096];
+        const ssize_t len = readlink("/proc/self/exe", exe, sizeof exe - 1);
+        if (len > 0) {
+            exe[len] = 0;
+            std::string dir(exe);
+            dir = dir.substr(0, dir.rfind('/'));
+            shapes = dir + "/../../tests/golden/replay_shapes.json";
+        }
+    }
+    std::vector<char> out(16384);
+    const int rc = reef_replay_run(shapes.empty() ? nullptr : shapes.c_str(), which, nofold, tables, out.data(), out.size());
+    if (rc == 0) printf("%s\n", out.data());
+    else fprintf(stderr, "reef_replay: %s\n", out.data());
+    return rc;
+}
+#endif

@@ -47,3 +47,32 @@ def commit(curve, doc: Sequence[int], width: int, full_rounds: int, partial_roun
             break
         m_ = (m_ + 1) // 2
     return array_to_ints(root)[0], levels
+
+
+def commit_arrays(curve, doc: np.ndarray, width: int, full_rounds: int, partial_rounds: int, round_constants: Sequence[int],
+                  mds: Sequence[Sequence[int]], tag_leaf: int, tag_node: int, want_tree: bool = True) -> Tuple[int, List[np.ndarray]]:
+    """The same call for documents too large for Python integers: -> (commitment, levels as (m, 4) uint64 arrays of canonical
+    limbs, level 0 first; empty when want_tree is False and only the root is copied back)."""
+    lib = _ffi.load()
+    rc = ints_to_array(list(round_constants))
+    m = ints_to_array([x for row in mds for x in row])
+    pp = PoseidonParams(width, full_rounds, partial_rounds, 0, rc.ctypes.data, m.ctypes.data,
+                        (ctypes.c_uint64 * 4)(*[(tag_leaf >> (64 * i)) & 0xFFFFFFFFFFFFFFFF for i in range(4)]),
+                        (ctypes.c_uint64 * 4)(*[(tag_node >> (64 * i)) & 0xFFFFFFFFFFFFFFFF for i in range(4)]))
+    d = np.ascontiguousarray(np.asarray(doc, dtype=np.uint32))
+    n = d.shape[0]
+    total = nodes(n)
+    tree = np.empty((total, 4), dtype=np.uint64) if want_tree else None
+    root = np.zeros((1, 4), dtype=np.uint64)
+    check(lib.reef_merkle_commit(curve_id(curve), ctypes.byref(pp), d.ctypes.data, n, REEF_HOST, False, tree.ctypes.data if want_tree else None, REEF_HOST,
+                                 root.ctypes.data))
+    levels: List[np.ndarray] = []
+    if want_tree:
+        m_, off = (n + 1) // 2, 0
+        while True:
+            levels.append(tree[off:off + m_])
+            off += m_
+            if m_ <= 1:
+                break
+            m_ = (m_ + 1) // 2
+    return array_to_ints(root)[0], levels

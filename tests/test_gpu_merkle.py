@@ -63,6 +63,34 @@ def test_large_document_properties(gpu_lib):
     assert M.root_from_path([int(v) for v in doc[:0]] or doc.tolist(), q, M.path_wits(doc.tolist(), tree, q), p) == root
 
 
+def test_cfg5_document_size(gpu_lib):
+    """BASELINE.json configs[4]: a 64 MiB document is 2^26 + 2 symbols padded to 2^27 (src/backend/framework.rs:997-1008;
+    tree: src/backend/merkle_tree.rs:25-80).  The whole tree (2^27 - 1 nodes, 4 GiB) comes back to the host; the oracle hashes
+    a sample of it: leaves, interior nodes of every level, and every node from 1024 nodes up."""
+    from reef_amd import merkle
+    p = M.standin_params()
+    n = 1 << 27
+    rng = np.random.default_rng(27)
+    doc = rng.integers(0, 131, size=n, dtype=np.uint32)
+    root, tree = merkle.commit_arrays("pallas", doc, p.t, p.rf, p.rp, p.rc, p.mds, p.tag_leaf, p.tag_node)
+    assert [len(l) for l in tree] == [1 << (26 - h) for h in range(27)]
+
+    def val(level, i):
+        return sum(int(x) << (64 * k) for k, x in enumerate(tree[level][i]))
+    for i in [0, 1, (1 << 26) - 1] + [int(x) for x in rng.integers(0, 1 << 26, size=24)]:
+        assert val(0, i) == M.hash_query([2 * i, int(doc[2 * i]), 2 * i + 1, int(doc[2 * i + 1])], p)
+    for h in range(0, 16):                                        # interior nodes of the big levels, sampled
+        m = len(tree[h + 1])
+        for i in [0, m - 1] + [int(x) for x in rng.integers(0, m, size=6)]:
+            assert val(h + 1, i) == M.hash_query([val(h, 2 * i), val(h, 2 * i + 1)], p)
+    for h in range(16, 26):                                       # 1024 nodes and fewer: every node
+        for i in range(len(tree[h + 1])):
+            assert val(h + 1, i) == M.hash_query([val(h, 2 * i), val(h, 2 * i + 1)], p)
+    assert val(26, 0) == root
+    root_only, no_tree = merkle.commit_arrays("pallas", doc, p.t, p.rf, p.rp, p.rc, p.mds, p.tag_leaf, p.tag_node, want_tree=False)
+    assert root_only == root and no_tree == []
+
+
 @pytest.mark.parametrize("rp", [0, 1, 2, 8, 9, 17, 57])
 def test_sparse_partial_rounds_equal_the_dense_definition(rp, gpu_lib):
     """The GPU runs the partial rounds in their sparse form (constants derived on the host); the oracle applies the

@@ -44,8 +44,24 @@ def test_bench_with_two_ranks(sharding, logn, gpu_lib):
     assert line["n_gpus"] == 2 and cfg["check"] == "dlog-ok"
     assert cfg["partials_differ_from_total"] is True             # each rank really held a partial sum
     assert "gloo" in cfg["exchange"]                             # labelled as the host-staged fallback, not as RCCL
+    assert cfg["rccl"] == {"ranks_seen": 2, "backend": "gloo", "stream_ordered": False}
     if sharding == "points":
         assert line["scaling"] == "weak" and cfg["total_points"] == 2 << logn and cfg["sharding"] == "points"
+        # one SCALE run yields both strong splits as well: ONE 2^logn-point MSM by window and by points on the same ranks,
+        # both combined points checked against the discrete log of the whole MSM (inside cfg["check"])
+        ss = cfg["strong_scaling"]
+        assert ss["one_msm_points"] == 1 << logn and ss["windows_ms_per_step"] > 0 and ss["points_ms_per_step"] > 0
+        assert set(ss["speedup_vs_1"]) == {"windows", "points"} and ss["one_gpu_ms_per_step"] == pytest.approx(line["ms_per_step"])
     else:
         assert line["scaling"] == "strong" and cfg["total_points"] == 1 << logn and cfg["sharding"].startswith("windows")
+        assert cfg["strong_scaling"] is None
     assert line["value"] > 0 and line["roofline"]["kernel_ms"] > 0
+
+
+def test_world_size_must_match_gpus(gpu_lib):
+    """--gpus N under a launcher with another world size is refused instead of quietly measuring something else."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "4", "--backend", "gloo", "--logn", "12", "--steps", "1",
+           "--warmup", "0", "--no-cpu-baseline"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"), cwd=ROOT)
+    assert out.returncode != 0 and "WORLD_SIZE=2" in out.stderr

@@ -1,0 +1,55 @@
+"""The MSM sequence of `reef --prove` (eniac/Reef src/backend/framework.rs:664-723: prove_step per batch, CompressedSNARK::prove,
+the consistency proof) replayed through the C ABI by the C++ harness, under pytest: every per-step commitment is checked
+inside the harness against its discrete-logarithm closed form (host big-integer arithmetic + a one-point key), with the
+per-step scalars in host memory and the commitments returned to the host, as nova hands them over.
+
+The MSM lengths are those of tests/golden/replay_shapes.json (oracle/gen_replay_shapes.py: Reef's cost model restated,
+tests/test_costs_oracle.py).  Both serving paths of a resident key are covered: the bucket pipeline and the byte tables.
+"""
+import json
+import os
+import subprocess
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _expected_checks(shape):
+    timed_steps = max(shape["steps"], 3)            # the harness times at least three steps
+    return 2 + 4 * timed_steps + 4                  # warm-up W1/W2, four commitments per step, the two batched pairs
+
+
+@pytest.mark.parametrize("cfg", ["cfg3", "cfg4"])
+@pytest.mark.parametrize("tables", [False, True])
+def test_replay_checks_every_commitment(cfg, tables, gpu_lib):
+    from reef_amd import replay
+    line = replay.run(cfg, nofold=True, tables=tables)
+    shape = next(s for name, s in replay.shapes().items() if cfg in name)
+    assert line["replay"] == shape["name"]
+    assert (line["w1"], line["c1"], line["w2"], line["c2"]) == (shape["w1"], shape["c1"], shape["w2"], shape["c2"])   # nothing typed into the harness
+    assert line["commitments_checked_against_dlog"] == _expected_checks(shape)
+    assert line["steps"] == shape["steps"] and line["ipa_pallas_rounds"] == (line["key_pallas"]).bit_length() - 1
+    assert line["total_prove_msm_ms"] > 0 and line["ms_per_step"] > 0
+    assert ("built with the keys" in line["byte_tables"]) == tables
+
+
+def test_replay_with_generator_folds(gpu_lib):
+    """The zero-patch drop-in path: cross terms over re-keyed contexts + reef_fold per round (the smallest config keeps it short)."""
+    from reef_amd import replay
+    line = replay.run("cfg1", nofold=False, tables=False)
+    shape = next(s for name, s in replay.shapes().items() if "cfg1" in name)
+    assert line["commitments_checked_against_dlog"] == _expected_checks(shape)
+    assert "generator fold" in line["ipa"]
+
+
+def test_replay_executable(gpu_lib):
+    """The same harness as a program (what profiles/*replay*.jsonl were recorded with): exit code 0 and one JSON line."""
+    exe = os.path.join(ROOT, "reef_amd", "_lib", "reef_replay")
+    out = subprocess.run([exe, "cfg3", "nofold"], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = json.loads(out.stdout.strip().splitlines()[-1])
+    assert line["commitments_checked_against_dlog"] >= 18
+    bad = subprocess.run([exe, "cfg3", "nofold", "shapes=/nonexistent.json"], capture_output=True, text=True, timeout=600)
+    assert bad.returncode != 0 and "shapes" in bad.stderr

@@ -73,7 +73,8 @@ def test_golden_explicit_c(golden, cref):
         cid = CID[case["curve"]]
         bases, sm, sc = _explicit_arrays(case)
         for scal, mont in ((sm, True), (sc, False)):
-            for fn in (cref.msm_naive, lambda *a, **k: cref.msm_pippenger(*a, threads=2, **k)):
+            for fn in (cref.msm_naive, lambda *a, **k: cref.msm_pippenger(*a, threads=2, **k),
+                       lambda *a, **k: cref.msm_pippenger_windows(*a, threads=3, **k)):
                 r = fn(cid, bases, scal, mont=mont)
                 assert cref.compress(cid, r).hex() == case["expect_compressed"], case["label"]
 
@@ -88,6 +89,9 @@ def test_golden_seeded_c(golden, cref):
         assert hashlib.sha256(bases.tobytes() + sc.tobytes()).hexdigest() == case["input_sha256"]
         r = cref.msm_pippenger(cid, bases, sc, threads=4)
         assert cref.compress(cid, r).hex() == case["expect_compressed"], (case["curve"], n, case["kind"])
+        for threads in (1, 5):   # the window-parallel form on the thread pool (the timed cpu_baseline)
+            r = cref.msm_pippenger_windows(cid, bases, sc, threads=threads)
+            assert cref.compress(cid, r).hex() == case["expect_compressed"], (case["curve"], n, case["kind"], threads)
 
 
 @pytest.mark.parametrize("name", ["pallas", "vesta"])
@@ -145,3 +149,20 @@ def test_dlog_property_c_large(cref):
         r = cref.msm_pippenger(cid, bases, sc, threads=4)
         canon = [C.scalar_from_mont(cref.limbs_to_int(sc[i])) for i in range(n)]
         assert cref.compress(cid, r) == C.compress(msm_via_dlog(C, canon, 11, 7))
+        assert cref.compress(cid, cref.msm_pippenger_windows(cid, bases, sc, threads=8)) == cref.compress(cid, r)
+        assert cref.compress(cid, cref.msm_pippenger_windows(cid, bases, sc, threads=2, n=n - 37)) == \
+            cref.compress(cid, cref.msm_pippenger(cid, bases[:n - 37].copy(), sc[:n - 37].copy(), threads=2))
+
+
+def test_c_threaded_fold_equals_serial(cref):
+    for cid in (0, 1):
+        gens = cref.gen_bases_ap(cid, 5, 9, 70)
+        w1, w2 = 0x1234567890ABCDEF1234567890ABCDEF1234567890ABCDEF, 0x0FEDCBA987654321
+        assert (cref.fold_mt(cid, gens, w1, w2, threads=4) == cref.fold(cid, gens, w1, w2)).all()
+
+
+def test_window_plan_keeps_the_window_of_the_whole_input():
+    from oracle import pasta_ref
+    c1, s1 = pasta_ref.window_plan(1 << 20, 1)
+    c256, s256 = pasta_ref.window_plan(1 << 20, 256)
+    assert c1 >= 14 and c256 >= 12 and s256 * ((256 + c256 - 1) // c256) >= 128   # many threads: tiles, not a smaller window
