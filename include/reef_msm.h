@@ -82,10 +82,12 @@ typedef struct {
                                (all windows share one bucket set); otherwise windows w and w'
                                share buckets iff w % G == w' % G */
     uint32_t chunk;         /* sorted entries per accumulation thread (L0); 0 = default */
-    uint32_t byte_tables;   /* bucket_groups = 1, 1024 < n <= 65536: the sort-free byte tables (256 KiB per point).  0 = built in
-                               the background from reef_msm_ctx_create on (14-38 ms on a low-priority stream; the bucket
-                               pipeline serves the key until they are ready), 1 = reef_msm_ctx_create returns when they
-                               are ready, 2 = none.  See reef_msm_ctx_byte_tables. */
+    uint32_t byte_tables;   /* bucket_groups = 1, 1024 < n <= 65536: the sort-free byte tables (256 KiB per point, 14-38 ms to
+                               build).  OPT-IN: 0 = the process-wide policy (none, unless REEF_MSM_WIDE=1 is set: then as 3),
+                               1 = built inside reef_msm_ctx_create, 2 = never, 3 = built in the background on a
+                               low-priority stream of the key's own (the bucket pipeline serves the key until they are
+                               ready; calls that run beside the build are slowed by it).  For keys that live long enough
+                               to earn them (a prover service).  See reef_msm_ctx_byte_tables. */
     int32_t device;         /* HIP device ordinal; -1 = current device */
     uint32_t reserved[3];
 } reef_msm_opts;

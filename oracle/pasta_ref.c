@@ -469,6 +469,9 @@ static void pool_run(int threads, size_t units, unit_fn fn, void *ctx) {
     pthread_mutex_unlock(&POOL_JOB);
 }
 
+/* threads parked in the pool (what pthread_create granted so far) */
+int pasta_ref_pool_size(void) { return POOL.nworkers; }
+
 /* ------------------------------------------------- window-parallel Pippenger ----
  * The shape of pasta-msm's own CPU path [recalled, the crate is not in /root/reference]: ONE window size for the whole
  * input, Booth-recoded signed digits (2^(c-1) buckets per window), the (window, slice of the points) tiles dealt out to

@@ -40,6 +40,7 @@ void pasta_ref_msm_pippenger(int curve, const uint64_t *bases_affine, const uint
 void pasta_ref_msm_pippenger_windows(int curve, const uint64_t *bases_affine, const uint64_t *scalars,
                                      size_t n, int scalars_are_mont, int threads, uint64_t *out_jacobian);
 unsigned pasta_ref_window_plan(size_t n, int threads, unsigned *slices_out);
+int pasta_ref_pool_size(void);   /* helper threads the pool holds (pthread_create may grant fewer than asked for) */
 
 /* Jacobian (96 B) -> affine (64 B, Montgomery; identity -> (0,0)) and 32-byte compressed form
  * (LE canonical x, y parity in bit 255; identity = zeros). */

@@ -92,6 +92,10 @@ def msm_pippenger_windows(curve: int, bases: np.ndarray, scalars: np.ndarray, mo
     return out
 
 
+def pool_size() -> int:
+    return int(lib().pasta_ref_pool_size())
+
+
 def window_plan(n: int, threads: int) -> tuple[int, int]:
     s = ctypes.c_uint(0)
     c = lib().pasta_ref_window_plan(n, threads, ctypes.byref(s))

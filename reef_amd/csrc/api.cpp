@@ -436,6 +436,7 @@ static reef_status pippenger_cached(int curve, reef_jacobian *out, const reef_af
         if (g_cache_bytes.load() + cost > cache_budget()) return REEF_OK;
         reef_msm_opts o = {};
         o.bucket_groups = 1;
+        o.byte_tables = 2;                             // never for a key the caller did not create: 256 KiB per point would dwarf the budget charged above
         o.device = -1;
         void *raw = reef_device_alloc(bytes);
         if (!raw) return REEF_OK;                       // no memory for a copy: keep serving this key uncached

@@ -322,7 +322,7 @@ static std::string replay_body(const Shape &shape, bool nofold, bool tables, con
         }
         reef_msm_opts o = {};
         o.bucket_groups = 1;  // commitment keys are fixed for the life of PublicParams: pre-shift once
-        o.byte_tables = tables ? 1 : 2;   // explicit, so that the default policy (tables after 64 MSMs on a key) cannot switch paths mid-run
+        o.byte_tables = tables ? 1 : 2;   // explicit: built with the key, or never (no switch of paths mid-run)
         o.device = -1;
         t0 = clk::now();
         CK(reef_msm_ctx_create(&c.key, c.id, c.d_gens, c.n, REEF_DEVICE, &o));

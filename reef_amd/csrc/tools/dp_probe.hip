@@ -9,7 +9,8 @@
 //      t  = C1 - h               = -hi, exact
 //      l  = fma(a, b, t)         = ab - hi = lo in [-2^50, 2^50], exact
 //      lo_col[k]     += l        |sum of 5| <= 5 * 2^50 < 2^53: exact
-//      hi_col[k + 1] -= t        multiples of 2^51 below 5 * 2^102: exact
+//      hi_col[k + 1] -= t        multiples of 2^51: exact while the sum stays below 2^104, i.e. for four terms -- the
+//                                fifth term of the middle column goes to an accumulator of its own
 // = FIVE instructions per limb product, 125 for the 25 of a product, before any modular reduction (a chained
 // h' = fma(a', b', h) saves the subtraction only while C1 + hi + hi' stays below 2^104: two products, and then costs
 // the difference h - h' back; summing the bit patterns of h and l with 64-bit integer additions -- Emmart's form --
@@ -43,13 +44,14 @@ __device__ __forceinline__ void int_columns(const u32 (&a)[9], const u32 (&b)[9]
 }
 
 // ---- multiply part, FP64: column sums of five 51-bit limbs, high and low halves (125 DP instructions) ----
-// lo[k] = sum of the low halves of column k; hi[k] = sum of the high halves of column k - 1 (multiples of 2^51)
-__device__ __forceinline__ void dp_columns(const double (&a)[5], const double (&b)[5], double (&lo)[9], double (&hi)[10]) {
+// lo[k] = sum of the low halves of column k; hi[k] = sum of the high halves of column k - 1 (multiples of 2^51); hi[10] = the
+// fifth high half of the middle column, which belongs to hi[5] (five terms of up to 2^102 do not fit 53 bits above 2^51)
+__device__ __forceinline__ void dp_columns(const double (&a)[5], const double (&b)[5], double (&lo)[9], double (&hi)[11]) {
     const double C1 = 0x1.8p+103;   // 3 * 2^102
 #pragma unroll
     for (int k = 0; k < 9; ++k) lo[k] = 0.0;
 #pragma unroll
-    for (int k = 0; k < 10; ++k) hi[k] = 0.0;
+    for (int k = 0; k < 11; ++k) hi[k] = 0.0;
 #pragma unroll
     for (int i = 0; i < 5; ++i)
 #pragma unroll
@@ -58,7 +60,7 @@ __device__ __forceinline__ void dp_columns(const double (&a)[5], const double (&
             const double t = C1 - h;
             const double l = __builtin_fma(a[j], b[i], t);
             lo[i + j] += l;
-            hi[i + j + 1] -= t;
+            hi[(i == 4 && j == 0) ? 10 : i + j + 1] -= t;
         }
 }
 
@@ -75,7 +77,7 @@ __device__ void pack_int(const u64 (&t)[17], u64 (&out)[8]) {
         if (s > 35 && w + 1 < 8) out[w + 1] |= (u64)limbs[k] >> (64 - s);
     }
 }
-__device__ void pack_dp(const double (&lo)[9], const double (&hi)[10], u64 (&out)[8]) {
+__device__ void pack_dp(const double (&lo)[9], const double (&hi)[11], u64 (&out)[8]) {
     i128 acc = 0;
     u64 limbs[11];
     for (int k = 0; k < 10; ++k) {
@@ -83,6 +85,7 @@ __device__ void pack_dp(const double (&lo)[9], const double (&hi)[10], u64 (&out
         const long long h = (long long)(hi[k] * 0x1p-51);   // exact: hi[k] is a multiple of 2^51
         acc += l;
         acc += h;
+        if (k == 5) acc += (long long)(hi[10] * 0x1p-51);
         limbs[k] = (u64)acc & MASK51;
         acc >>= 51;
     }
@@ -130,7 +133,7 @@ __global__ void __launch_bounds__(256) k_verify(u32 cases_per_thread, u64 seed, 
         split_operand(y, b29, b51);
         u64 t[17];
         int_columns(a29, b29, t);
-        double lo[9], hi[10];
+        double lo[9], hi[11];
         dp_columns(a51, b51, lo, hi);
         u64 pi[8], pd[8];
         pack_int(t, pi);
@@ -167,13 +170,13 @@ __global__ void __launch_bounds__(256) k_time_dp(u32 *out, u32 seed) {
     for (int it = 0; it < ITERS; ++it) {
 #pragma unroll
         for (int i = 0; i < 5; ++i) { asm volatile("" : "+v"(a[i])); asm volatile("" : "+v"(b[i])); }   // opaque: nothing of the product is loop-invariant
-        double lo[9], hi[10];
+        double lo[9], hi[11];
         dp_columns(a, b, lo, hi);
         u64 x = 0;
 #pragma unroll
         for (int k = 0; k < 9; ++k) x ^= (u64)__double_as_longlong(lo[k]);   // every column is live: the same kind of v_xor_b32 overhead (36)
 #pragma unroll
-        for (int k = 1; k < 10; ++k) x ^= (u64)__double_as_longlong(hi[k]);
+        for (int k = 1; k < 11; ++k) x ^= (u64)__double_as_longlong(hi[k]);
         a[0] = __builtin_fabs(lo[0]);                             // an integer below 2^51 again (|lo| <= 2^50)
         acc += (double)(u32)x;
     }

@@ -149,7 +149,7 @@ class MsmContext:
         return {"window_bits": c.value, "windows": w.value, "bucket_groups": g.value, "tables": t.value}
 
     def has_byte_tables(self) -> bool:
-        """True when this key's MSMs are served from its byte tables (ready: built in the background from creation on, reef_msm.h)."""
+        """True when this key's MSMs are served from its byte tables (opt-in: byte_tables = 1 at creation, 3 in the background; reef_msm.h)."""
         return bool(self._lib.reef_msm_ctx_byte_tables(self._h))
 
     def set_window_split(self, rank: int, world: int) -> None:

@@ -661,9 +661,11 @@ def test_byte_tables_at_prover_sizes_dlog_property(name, logn, kind, gpu_lib):
     assert msm.compress(name, got_m) == dlog(m)
 
 
-def test_byte_tables_are_built_in_the_background_by_default(gpu_lib, cref):
-    """Default policy: the tables of an eligible key are built on a stream of their own from reef_msm_ctx_create on; the bucket
-    pipeline serves the key meanwhile, the switch changes no result, clones share the tables, re-keying drops them."""
+def test_byte_tables_built_in_the_background_on_request(gpu_lib, cref):
+    """byte_tables = 3: the tables of an eligible key are built on a stream of their own from reef_msm_ctx_create on; the bucket
+    pipeline serves the key meanwhile, the switch changes no result, clones share the tables, re-keying drops them (a build in
+    flight is told to stop: the levels still queued return at once).  The DEFAULT (byte_tables = 0) builds none: the tables cost
+    256 KiB per point and their build slows the calls it runs beside, so a key gets them only when its owner asks."""
     import os
     import time
     from reef_amd import msm
@@ -673,7 +675,13 @@ def test_byte_tables_are_built_in_the_background_by_default(gpu_lib, cref):
     bases = cref.gen_bases_ap(cid, 9, 2, n)
     sc = cref.gen_scalars(cid, 4, n)
     want = cref.compress(cid, cref.msm_pippenger(cid, bases, sc, threads=8))
-    with msm.MsmContext(cid, bases, bucket_groups=1) as ctx:
+    if os.environ.get("REEF_MSM_WIDE") != "1":
+        with msm.MsmContext(cid, bases, bucket_groups=1) as dflt:            # the default policy: no tables, whatever the key has served
+            for _ in range(3):
+                assert msm.compress(cid, dflt.msm(sc)) == want
+            time.sleep(0.2)
+            assert not dflt.has_byte_tables()
+    with msm.MsmContext(cid, bases, bucket_groups=1, byte_tables=3) as ctx:
         clone = ctx.clone()
         seen = set()
         deadline = time.time() + 20
@@ -689,10 +697,16 @@ def test_byte_tables_are_built_in_the_background_by_default(gpu_lib, cref):
         clone.close()
         bases2 = cref.gen_bases_ap(cid, 77, 3, n)                              # re-keying: the old tables must not serve the new key
         ctx.set_bases(bases2)
-        assert msm.compress(cid, ctx.msm(sc)) == cref.compress(cid, cref.msm_pippenger(cid, bases2, sc, threads=8))
+        want2 = cref.compress(cid, cref.msm_pippenger(cid, bases2, sc, threads=8))
+        assert msm.compress(cid, ctx.msm(sc)) == want2
+        t0 = time.time()
+        for k in range(4):                                                     # re-keying in a loop: every call stops the build the previous one started
+            ctx.set_bases(bases if k % 2 == 0 else bases2)
+            assert msm.compress(cid, ctx.msm(sc)) == (want if k % 2 == 0 else want2)
+        assert time.time() - t0 < 5.0
     with msm.MsmContext(cid, bases, bucket_groups=1, byte_tables=2) as none:
         assert msm.compress(cid, none.msm(sc)) == want and not none.has_byte_tables()
-    with msm.MsmContext(cid, bases, bucket_groups=1) as gone:               # destroyed while the build is in flight
+    with msm.MsmContext(cid, bases, bucket_groups=1, byte_tables=3) as gone:               # destroyed while the build is in flight
         pass
     with msm.MsmContext(cid, bases[:1000].copy(), bucket_groups=1, byte_tables=1) as small:   # <= 1024 points: the nibble tables serve it
         assert not small.has_byte_tables()
@@ -709,7 +723,7 @@ def test_byte_tables_switch_under_concurrent_callers(gpu_lib, cref):
     bases = cref.gen_bases_ap(cid, 314, 15, n)
     sc = cref.gen_scalars(cid, 27, n)
     want = cref.compress(cid, cref.msm_pippenger(cid, bases, sc, threads=8))
-    with msm.MsmContext(cid, bases, bucket_groups=1) as ctx:
+    with msm.MsmContext(cid, bases, bucket_groups=1, byte_tables=3) as ctx:
         clones = [ctx.clone() for _ in range(4)]
         bad, calls = [], [0] * 4
         stop = time.time() + 1.5
