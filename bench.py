@@ -46,6 +46,8 @@ def parse():
     p.add_argument("--bucket-groups", type=int, default=-1, help="-1: engine default for the bench key")
     p.add_argument("--chunk", type=int, default=0)
     p.add_argument("--streams", type=int, default=3, help="MSMs in flight (clones of the key on separate HIP streams)")
+    p.add_argument("--batch", type=int, default=1, help="N = 1 only: MSMs per step, issued as ONE batched call on the same resident key (reef_msm_rows with "
+                                                        "rows = batch: one pass of the sort / accumulate / reduce pipeline for all of them)")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--cpu-seconds", type=float, default=12.0)
     p.add_argument("--no-check", action="store_true")
@@ -82,6 +84,21 @@ def point_of_dlog(curve_name, k):
     return C.compress(C.mul(k % C.order, C.gen))
 
 
+def cpu_quota():
+    """CPUs the container may use (cgroup v2 cpu.max / v1 cfs quota), or None when unlimited: os.cpu_count() shows the host's."""
+    try:
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()
+        return None if q == "max" else float(q) / float(p)
+    except (OSError, ValueError):
+        pass
+    try:
+        q = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+        p = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+        return None if q <= 0 else q / p
+    except (OSError, ValueError):
+        return None
+
+
 def cpu_baseline(curve_id, seconds):
     """Oracle C Pippenger on the host cores: the window-parallel form on a persistent thread pool (pasta-msm's shape: one
     window size for the whole input, Booth digits, (window, point-slice) tiles dealt out to the pool)."""
@@ -96,11 +113,17 @@ def cpu_baseline(curve_id, seconds):
     t0 = time.perf_counter()
     R.msm_pippenger_windows(curve_id, bases, sc, threads=1, n=n // 8)
     one_thread_rate = (n // 8) / (time.perf_counter() - t0)
+    quota = cpu_quota()
+    cand = {cores, max(1, cores // 2), max(1, cores // 4), max(1, cores // 8), max(1, cores // 16)}
+    if quota:
+        cand |= {min(cores, max(1, int(quota))), min(cores, max(1, int(2 * quota)))}
     best = None
-    for t in sorted({cores, max(1, cores // 2), max(1, cores // 4), max(1, cores // 8), max(1, cores // 16)}, reverse=True):
-        t0 = time.perf_counter()
-        R.msm_pippenger_windows(curve_id, bases, sc, threads=t)
-        dt = time.perf_counter() - t0
+    for t in sorted(cand, reverse=True):
+        dt = 1e30
+        for _ in range(2):
+            t0 = time.perf_counter()
+            R.msm_pippenger_windows(curve_id, bases, sc, threads=t)
+            dt = min(dt, time.perf_counter() - t0)
         if best is None or dt < best[1]:
             best = (t, dt)
     threads, dt = best
@@ -122,10 +145,11 @@ def cpu_baseline(curve_id, seconds):
     value = n * reps / spent
     return {"value": value, "unit": "pairs/s", "cores": threads, "kind": "port", "per_thread": value / threads,
             "one_thread": one_thread_rate, "speedup_over_one_thread": value / one_thread_rate, "host_cores_visible": cores,
+            "container_cpu_quota": quota,
             "pool_helpers": R.pool_size(),
             "sample": f"{reps} x 2^{logn}-point Pallas MSM, uniform scalars, oracle/pasta_ref.c window-parallel Pippenger (c = {c}, {slices} point "
                       f"slices per window, persistent thread pool; a restatement, NOT the reference binary: Reef is Rust and cannot be built here), "
-                      f"{threads} threads on {cores} visible host cores (best of all / 1/2 / 1/4 / 1/8 / 1/16; speed-up over one thread {value / one_thread_rate:.0f}x)"}
+                      f"{threads} threads on {cores} visible host cores (best of all / 1/2 / 1/4 / 1/8 / 1/16 and the container's CPU quota of {quota if quota else 'none'}; speed-up over one thread {value / one_thread_rate:.0f}x)"}
 
 
 def replay_leg(cpu_seconds_ok=True, cpu_threads=None):
@@ -202,7 +226,8 @@ def main():
 
     # synthetic inputs, generated on the device: rank r owns bases B_i, i in [r*n, (r+1)*n)
     bases = msm.gen_bases(a.curve, k0 + owner * n * d, d, n, device=True)
-    scalars = msm.gen_scalars(a.curve, seed, n, kind=kind, mont=True, device=True)
+    B = a.batch if not multi else 1
+    scalars = msm.gen_scalars(a.curve, seed, n * B, kind=kind, mont=True, device=True)
     ctx0 = msm.MsmContext(a.curve, bases, n, window_bits=a.window_bits, bucket_groups=groups, chunk=a.chunk)
     if by_windows:
         ctx0.set_window_split(rank, max(world, 1))
@@ -214,7 +239,7 @@ def main():
     # per-context device buffers: local partial (96 B), gathered partials, combined result
     parts = [torch.zeros(96, dtype=torch.uint8, device=dev) for _ in range(nctx)]
     gathered = [torch.zeros(96 * a.gpus, dtype=torch.uint8, device=dev) for _ in range(nctx)]
-    results = [torch.zeros(96, dtype=torch.uint8, device=dev) for _ in range(nctx)]
+    results = [torch.zeros(96 * B, dtype=torch.uint8, device=dev) for _ in range(nctx)]
     # the exchange of N > 1 (reef_amd/distributed.py: all-gather of the 96-byte partial sums + on-device add); with RCCL
     # the collective is ordered on the MSM's own HIP stream, so a step needs no host sync
     from reef_amd.distributed import PartialSumExchange
@@ -235,7 +260,9 @@ def main():
     def step(i):
         j = i % nctx
         c = ctxs[j]
-        if not multi:
+        if not multi and B > 1:
+            c.msm_rows(scalars, B, n, max_scalar_bits=255, out=results[j].data_ptr())
+        elif not multi:
             c.msm(scalars, n, out=results[j].data_ptr())
         else:
             c.msm(scalars, n, out=parts[j].data_ptr())
@@ -405,10 +432,13 @@ def main():
     if not a.no_check:
         # size-independent parity check of the last result (outside the timed region): bases are an arithmetic
         # progression, so every MSM over them has a known discrete log
-        canon = msm.gen_scalars(a.curve, seed, n, kind=kind, mont=False)
-        my_dlog = dlog_of_msm(a.curve, canon, k0, d, owner * n)
+        canon = msm.gen_scalars(a.curve, seed, n * B, kind=kind, mont=False)
+        my_dlog = dlog_of_msm(a.curve, canon[:n], k0, d, owner * n)
         if not multi:
-            ok = msm.compress(a.curve, final_result.view(np.uint64)) == point_of_dlog(a.curve, my_dlog)
+            ok = msm.compress(a.curve, final_result[:96].view(np.uint64)) == point_of_dlog(a.curve, my_dlog)
+            for r in range(1, B):             # every MSM of the batch
+                ok = ok and msm.compress(a.curve, final_result[96 * r:96 * (r + 1)].view(np.uint64)) == point_of_dlog(
+                    a.curve, dlog_of_msm(a.curve, canon[r * n:(r + 1) * n], k0, d, 0))
         else:
             cdev = dev if a.backend == "nccl" else "cpu"
             got_total = msm.compress(a.curve, final_result.view(np.uint64))
@@ -450,9 +480,9 @@ def main():
                     break
             except (OSError, KeyError, ValueError):
                 pass
-        pairs = n * (1 if by_windows else a.gpus) * a.steps
+        pairs = n * B * (1 if by_windows else a.gpus) * a.steps
         value = pairs / elapsed
-        achieved = BYTES_PER_PAIR * n / (acc_ms * 1e-3) / 1e9 if acc_ms > 0 else None
+        achieved = BYTES_PER_PAIR * n * B / (acc_ms * 1e-3) / 1e9 if acc_ms > 0 else None
         eff_windows = min(plan["windows"], -(-255 // plan["window_bits"]))   # windows that hold scalar bits (scalars < 2^255)
         out = {
             "metric": "msm_scalar_point_pairs_per_sec", "value": value, "unit": "pairs/s", "n_gpus": a.gpus,
@@ -466,7 +496,7 @@ def main():
                                             "threads each on its own clone of the resident key; PCIe-inclusive, measured after the timed region, never `value`",
                        "points_per_gpu": n, "total_points": n * (1 if by_windows else a.gpus), "window_bits": plan["window_bits"],
                        "windows": plan["windows"], "bucket_groups": plan["bucket_groups"], "tables": plan["tables"],
-                       "streams": nctx, "sharding": ("windows (w = rank mod N)" if by_windows else "points") if a.gpus > 1 else "none",
+                       "streams": nctx, "msms_per_step": B, "sharding": ("windows (w = rank mod N)" if by_windows else "points") if a.gpus > 1 else "none",
                        "exchange": ("none" if a.gpus == 1 else "rccl all_gather of 96 B partials + on-device add" if a.backend == "nccl"
                                     else "HOST-STAGED gloo all_gather of 96 B partials (debug fallback, not RCCL) + on-device add"),
                        "check": check, "partials_differ_from_total": partials_differ, "msm_ms_stream": tot_ms,
@@ -475,7 +505,7 @@ def main():
             "roofline": {"bound": "hbm", "kernel": "k_accum0 (bucket accumulation)", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": traffic,
                          "traffic_source": traffic_src,
-                         "kernel_ms": acc_ms, "algorithmic_bytes_per_launch": BYTES_PER_PAIR * n,
+                         "kernel_ms": acc_ms, "algorithmic_bytes_per_launch": BYTES_PER_PAIR * n * B,
                          "note": f"kernel_ms = average launch duration with {nctx} MSMs in flight (launches stretch each other); single_stream = one MSM in flight",
                          "single_stream": ({"kernel_ms": single["kernel_ms"], "msm_ms": single["msm_ms"],
                                             "achieved": BYTES_PER_PAIR * n / (single["kernel_ms"] * 1e-3) / 1e9,

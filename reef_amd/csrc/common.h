@@ -1,5 +1,6 @@
 // Host-side plumbing shared by the per-curve engines and the C ABI (not part of the ABI).
 #pragma once
+#include <atomic>
 #include <hip/hip_runtime.h>
 #include <stddef.h>
 #include <stdint.h>
@@ -26,11 +27,15 @@ void set_error(const char *fmt, ...) __attribute__((format(printf, 1, 2)));
     } while (0)
 
 // Grow-only device buffer (steady state performs no allocation).
+// Bumped whenever a workspace buffer is (re)allocated or released: captured hipGraphs hold raw device pointers and are
+// dropped when the generation they were captured under is gone (engine.inc, run_core_graphed).
+inline std::atomic<uint64_t> g_devbuf_gen{0};
 struct DevBuf {
     void *p = nullptr;
     size_t cap = 0;
     reef_status ensure(size_t bytes) {
         if (bytes <= cap) return REEF_OK;
+        ++g_devbuf_gen;
         if (p) { (void)hipFree(p); p = nullptr; cap = 0; }
         size_t want = bytes + bytes / 8 + 256;
         REEF_HIP_TRY(hipMalloc(&p, want));
@@ -38,7 +43,7 @@ struct DevBuf {
         return REEF_OK;
     }
     void release() {
-        if (p) (void)hipFree(p);
+        if (p) { (void)hipFree(p); ++g_devbuf_gen; }
         p = nullptr;
         cap = 0;
     }

@@ -746,3 +746,42 @@ def test_byte_tables_switch_under_concurrent_callers(gpu_lib, cref):
         assert min(calls) > 3 and ctx.has_byte_tables()
         for c in clones:
             c.close()
+
+
+def test_captured_graph_path_gives_the_same_points(gpu_lib):
+    """REEF_MSM_GRAPH=1 (opt-in, read once per process): the bucket pipeline of a repeated call shape is captured as a hipGraph
+    the second time it is seen and replayed afterwards; results are those of the plain launches, across re-keying, other
+    lengths on the same ctx (workspace growth drops the captured graphs) and host / device scalars."""
+    import os
+    import subprocess
+    import sys
+    code = r"""
+import sys; sys.path.insert(0, '.')
+import numpy as np
+from oracle import pasta_ref as R
+from reef_amd import msm
+for cid in (0, 1):
+    n = 6000
+    bases = R.gen_bases_ap(cid, 31, 5, n); sc = R.gen_scalars(cid, 8, n); sc2 = R.gen_scalars(cid, 9, n, kind=1)
+    want = R.compress(cid, R.msm_pippenger(cid, bases, sc, threads=4)); want2 = R.compress(cid, R.msm_pippenger(cid, bases, sc2, threads=4))
+    with msm.MsmContext(cid, bases, bucket_groups=1, byte_tables=2) as ctx:
+        for k in range(5):                                   # plain, captured, replayed ...
+            assert msm.compress(cid, ctx.msm(sc)) == want, k
+            assert msm.compress(cid, ctx.msm(sc2)) == want2, k       # same staging buffer, other contents
+        m = 2500
+        wantm = R.compress(cid, R.msm_pippenger(cid, bases[:m].copy(), sc[:m].copy(), threads=4))
+        for k in range(4):
+            assert msm.compress(cid, ctx.msm(sc[:m].copy())) == wantm
+        big = R.gen_bases_ap(cid, 77, 3, 20000); scb = R.gen_scalars(cid, 3, 20000)
+        ctx.set_bases(big)                                    # re-keyed: captured launches of the old key are gone
+        wantb = R.compress(cid, R.msm_pippenger(cid, big, scb, threads=8))
+        d = msm.DeviceBuffer.from_host(scb); o = msm.DeviceBuffer(96)
+        for k in range(4):
+            assert msm.compress(cid, ctx.msm(scb)) == wantb
+            ctx.msm(d, 20000, out=o); ctx.sync()
+            assert msm.compress(cid, o.to_host(12)) == wantb
+print('graph-ok')
+"""
+    out = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, REEF_MSM_GRAPH="1"), capture_output=True, text=True, timeout=600,
+                         cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    assert "graph-ok" in out.stdout, out.stderr[-3000:]
