@@ -470,7 +470,7 @@ def main():
         # HBM traffic of the dominant kernel: PMC counters need their own rocprofv3 passes (never
         # combined with timing), so the value is read from the committed profile of this command
         traffic, traffic_src = None, None
-        for prof_name in ("r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+        for prof_name in ("r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
             try:
                 prof = json.load(open(os.path.join(ROOT, "profiles", prof_name)))
                 pc = prof["config"]

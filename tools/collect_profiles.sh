@@ -1,9 +1,10 @@
 #!/bin/bash
 # On the MI355X box: everything profiles/ holds for a round.  usage: tools/collect_profiles.sh OUTDIR [rNN]
-out=$(realpath -m $1); R=${2:-r02}; export REEF_ROUND=$R
+out=$(realpath -m $1); R=${2:-r03}; export REEF_ROUND=$R
 mkdir -p $out; export TMPDIR=/tmp; root=$GRAFT_REPO_ROOT
 python $root/bench.py > $out/${R}_bench.json 2> $out/${R}_bench.err
-(cd /tmp && rm -rf /tmp/ks && rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/ks -- python $root/bench.py --no-cpu-baseline > /dev/null 2>&1; cp /tmp/ks/*/*kernel_stats.csv $out/${R}_kernel_stats.csv)
+# per-kernel time of the same timed region: the legs that run other sizes through the same kernels after it (replay, CPU) are left out
+(cd /tmp && rm -rf /tmp/ks && rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/ks -- python $root/bench.py --no-cpu-baseline --no-replay > $out/${R}_bench_under_rocprof.json 2>/dev/null; cp /tmp/ks/*/*kernel_stats.csv $out/${R}_kernel_stats.csv)
 python $root/tools/pmc_traffic.py $out > $out/${R}_pmc_traffic.log 2>&1
 python $root/tools/pmc_valu.py $out/${R}_pmc_valu_issue.json > /dev/null 2>&1
 python $root/tools/sweep_plans.py 12 14 15 16 17 18 20 2>&1 | grep "##" > $out/${R}_latency_sweep.txt
@@ -31,7 +32,14 @@ PY
 python $root/tools/time_rows.py 1024 2048 131 > $out/${R}_rows_timing.txt 2>&1; python $root/tools/time_rows.py 4096 8192 7 >> $out/${R}_rows_timing.txt 2>&1
 python $root/tools/time_sumcheck.py 21 26 > $out/${R}_sumcheck_timing.txt 2>&1
 python $root/tools/time_mle.py > $out/${R}_mle_timing.txt 2>&1
-(python $root/tools/time_merkle.py; echo "# REEF_POSEIDON_DENSE=1 (partial rounds in the defining dense form), same box:"; REEF_POSEIDON_DENSE=1 python $root/tools/time_merkle.py | grep symbols) > $out/${R}_merkle_timing.txt 2>&1
+(python $root/tools/time_merkle.py 16 20 24 26 27; echo "# REEF_POSEIDON_DENSE=1 (partial rounds in the defining dense form), same box:"; REEF_POSEIDON_DENSE=1 python $root/tools/time_merkle.py 20 24 26 | grep symbols) > $out/${R}_merkle_timing.txt 2>&1
 python $root/tools/time_keygen.py $out/${R}_keygen_timing.json > /dev/null 2>&1
 python $root/tools/time_setup.py $out/${R}_setup_timing.json > /dev/null 2>&1
 (python $root/tools/time_host_scalars.py 20; python $root/tools/time_host_scalars.py 16; echo "# 2^16 points with byte tables:"; python $root/tools/time_host_scalars.py 16 --tables) > $out/${R}_host_scalars.txt 2>/dev/null
+# round 3 additions
+$root/reef_amd/_lib/dp_probe > $out/${R}_dp_probe.txt 2>&1
+python $root/tools/cpu_scaling.py 18 > $out/${R}_cpu_scaling.txt 2>&1
+python $root/tools/time_stateless.py > $out/${R}_stateless_pcie_inclusive.txt 2>&1
+(REEF_MSM_GRAPH=0 python $root/tools/time_graph.py; REEF_MSM_GRAPH=1 python $root/tools/time_graph.py) > $out/${R}_graph_latency.txt 2>&1
+python $root/tools/pmc_merkle.py $out/${R}_pmc_merkle.json > /dev/null 2>&1
+bash $root/tools/batch_sweep.sh $out/${R}_batch_sweep.txt > /dev/null 2>&1
