@@ -18,3 +18,23 @@ for gib in (1, 4.3, 8.6, 17.2, 8.6, 17.2):
     lib.reef_device_free(p)
     t2 = time.perf_counter()
     print(f"hipMalloc {gib:5.1f} GiB: {(t1 - t0) * 1e3:8.2f} ms, hipFree {(t2 - t1) * 1e3:8.2f} ms", flush=True)
+
+# first touch: the same allocation written twice (a fill kernel through reef_memcpy's device-to-device copy of a 1 GiB pattern)
+import ctypes  # noqa: E402
+pat = lib.reef_device_alloc(1 << 30)
+for gib in (8, 16, 8):
+    n = gib << 30
+    t0 = time.perf_counter()
+    p = lib.reef_device_alloc(n)
+    t_alloc = time.perf_counter() - t0
+    times = []
+    for rep in range(3):
+        t0 = time.perf_counter()
+        for k in range(gib):
+            lib.reef_memcpy(ctypes.c_void_p(p + (k << 30)), ctypes.c_void_p(pat), 1 << 30, 1, 1)
+        lib.reef_device_sync()
+        times.append((time.perf_counter() - t0) * 1e3)
+    t0 = time.perf_counter()
+    lib.reef_device_free(p)
+    t_free = time.perf_counter() - t0
+    print(f"{gib:3d} GiB: alloc {t_alloc * 1e3:.2f} ms; writing all of it: first {times[0]:.1f} ms, then {times[1]:.1f} / {times[2]:.1f} ms; free {t_free * 1e3:.2f} ms", flush=True)
