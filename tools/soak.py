@@ -30,7 +30,7 @@ while time.time() < t_end:
         want = R.compress(cid, R.msm_pippenger(cid, bases, sc, threads=16))
         groups = int(rng.choice([0, 1, 1, 3]))
         with msm.MsmContext(cid, bases, bucket_groups=groups, window_bits=int(rng.choice([0, 0, 7, 13, 15, 16])),
-                            byte_tables=int(rng.choice([0, 1, 1, 2])) if n <= 65536 else 0) as ctx:
+                            byte_tables=int(rng.choice([0, 1, 1, 2, 3])) if n <= 65536 else 0) as ctx:
             m = int(rng.integers(1, n + 1)) if rng.random() < 0.3 else n
             got = msm.compress(cid, ctx.msm(sc[:m].copy()))
             if m != n:
@@ -69,7 +69,7 @@ while time.time() < t_end:
         off = int(rng.integers(0, n_k))
         ln = int(rng.integers(1, n_k - off + 1))
         v = R.gen_scalars(cid, int(rng.integers(1, 1 << 30)), ln)
-        with msm.MsmContext(cid, gens0, bucket_groups=int(rng.choice([0, 1])), byte_tables=int(rng.choice([0, 1, 2]))) as ctx:
+        with msm.MsmContext(cid, gens0, bucket_groups=int(rng.choice([0, 1])), byte_tables=int(rng.choice([0, 1, 2, 3]))) as ctx:
             got = msm.compress(cid, ctx.msm_folded(v, w1s, w2s, off))
         assert got == R.compress(cid, R.msm_pippenger(cid, np.ascontiguousarray(gens[off:off + ln]), v)), ("folded", cid, n, k, off, ln)
     elif shape == 10:   # collisions everywhere: few distinct points (and their negatives), few distinct scalars
