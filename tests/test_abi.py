@@ -77,3 +77,20 @@ def test_fails_loudly_without_gpu():
     with pytest.raises(msm.ReefError) as e:
         msm.MsmContext("pallas", np.zeros((4, 8), dtype=np.uint64))
     assert e.value.status == 3  # REEF_ERR_NO_GPU: no silent CPU fallback
+
+
+def test_replay_library_exports_its_entry_point_and_fails_loudly_without_gpu():
+    """libreef_replay.so (the C++ host that issues Reef's MSM sequence) exports reef_replay_run; without a GPU it returns an
+    error code and a message, never a JSON line; a missing shapes file is an error as well."""
+    from reef_amd import replay
+    assert os.path.exists(replay.LIB_PATH), "run __graft_entry__.build() first"
+    assert os.path.exists(replay.SHAPES_PATH)
+    lib = ctypes.CDLL(replay.LIB_PATH)
+    assert hasattr(lib, "reef_replay_run")
+    if _ffi.load().reef_device_count() > 0:
+        pytest.skip("a GPU is present")
+    with pytest.raises(RuntimeError) as e:
+        replay.run("cfg3")
+    assert "failed with 3" in str(e.value)
+    shapes = replay.shapes()
+    assert set(n.split("_")[0] for n in shapes) == {"cfg1", "cfg3", "cfg4", "cfg5"}
