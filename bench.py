@@ -1,8 +1,10 @@
 #!/usr/bin/env python3
 """bench.py -- MSM scalar-point pairs/s of the MI355X backend (BASELINE.json metric).
 
-A step = one pass of the hot path over one batch of synthetic input: one 2^20-point Pallas MSM
-(BASELINE.json configs[1]) with the key and the scalars already resident in HBM.
+A step = one pass of the hot path over one batch of synthetic input: a batch of 32 MSMs of 2^20 Pallas points each
+(BASELINE.json configs[1]; --msms-per-step) with the key and the scalars already resident in HBM, issued one by one over
+three streams.  (Rounds 1-2 counted ONE MSM as a step: 20 steps were 26 ms, too short for an external sampler to see the GPU
+busy; `config.ms_per_msm` is the figure those rounds called ms_per_step.)
     python bench.py --gpus N --steps K --warmup W
 For N > 1 the driver launches one rank per GPU with torch.distributed.run; every rank owns its
 own 2^20 points of one N*2^20-point MSM (weak scaling), the 96-byte partial sums are exchanged
@@ -15,7 +17,7 @@ product path.
 What `value` includes: key AND scalars are resident in HBM when the timed region starts
 (`config.scalars` says so); the PCIe-inclusive rate of the same workload -- scalars in pinned host
 memory, result back in host memory, the same MSMs in flight -- is measured after the timed region and
-reported as `config.host_scalars_ms_per_step`; it is never `value`.
+reported as `config.host_scalars_ms_per_msm`; it is never `value`.
 """
 from __future__ import annotations
 
@@ -37,7 +39,10 @@ FMUL_PEAK = 1.57e11            # Montgomery products/s chip-wide, measured (reef
 def parse():
     p = argparse.ArgumentParser()
     p.add_argument("--gpus", type=int, default=1)
-    p.add_argument("--steps", type=int, default=100, help="timed steps (100 x 1.35 ms: long enough for an external sampler to see the GPU busy)")
+    p.add_argument("--steps", type=int, default=40, help="timed steps; a step is one batch of --msms-per-step MSMs (40 x 32 x 1.25 ms = 1.6 s: long enough "
+                                                        "for an external sampler to see the GPU busy)")
+    p.add_argument("--msms-per-step", type=int, default=32, help="MSMs of 2^logn points per step, issued one by one over the streams (the batch of synthetic "
+                                                                 "input one step passes through the hot path)")
     p.add_argument("--warmup", type=int, default=5)
     p.add_argument("--logn", type=int, default=20, help="log2 of points per GPU (BASELINE configs[1]: 20)")
     p.add_argument("--curve", default="pallas")
@@ -257,7 +262,7 @@ def main():
             exch.append(PartialSumExchange((lambda c_: (lambda g, cnt, out: c_.sum_points(g.data_ptr(), cnt, out.data_ptr())))(c),
                                            backend=a.backend, before_exchange=c.sync, stream_ctx=stream_ctx))
 
-    def step(i):
+    def one_msm(i):
         j = i % nctx
         c = ctxs[j]
         if not multi and B > 1:
@@ -275,13 +280,19 @@ def main():
 
     if multi and a.backend == "nccl":
         try:                       # first collective on an external stream: fall back to host-ordered calls if torch refuses
-            step(0)
+            one_msm(0)
             sync_all()
         except Exception as e:
             print(f"[bench] collective on the MSM stream failed ({e}); ordering by host sync instead", file=sys.stderr)
             for x in exch:
                 x.stream_ctx = None
     stream_ordered = bool(multi and a.backend == "nccl" and exch and all(x.stream_ctx is not None for x in exch))
+    MPS = max(1, a.msms_per_step)
+
+    def step(i):              # one step = one batch of MPS MSMs (each with its exchange when N > 1), round-robin over the streams
+        for k in range(MPS):
+            one_msm(i * MPS + k)
+
     for i in range(a.warmup):
         step(i)
     sync_all()
@@ -307,7 +318,7 @@ def main():
     calls = sum(s["calls"] for s in stats)
     acc_ms = sum(s["accumulate_ms"] for s in stats) / max(calls, 1)
     tot_ms = sum(s["total_ms"] for s in stats) / max(calls, 1)
-    last = (a.steps - 1) % nctx
+    last = (a.steps * MPS - 1) % nctx
     final_parts = parts[last].cpu().numpy().copy()
     final_result = results[last].cpu().numpy().copy()
 
@@ -321,7 +332,7 @@ def main():
     if multi and a.gpus > 1 and not by_windows:
         from reef_amd.distributed import shard_bounds
         cdev0 = dev if a.backend == "nccl" else "cpu"
-        ksteps = max(3, min(a.steps, 20))
+        ksteps = max(3, min(a.steps * MPS, 24))
 
         def make_exch(c):
             sc_ = None
@@ -374,14 +385,14 @@ def main():
         p_ms, p_res = timed(pctx, [make_exch(c) for c in pctx], scal0.ptr + 32 * lo, hi - lo)
         for c in pctx:
             c.close()
-        one_gpu_ms = elapsed / a.steps * 1e3      # what one GPU needs for a 2^logn-point MSM in the same regime (the weak region above)
+        one_gpu_ms = elapsed / (a.steps * MPS) * 1e3      # what one GPU needs for a 2^logn-point MSM in the same regime (the weak region above)
         strong = {"one_msm_points": n, "steps": ksteps, "in_flight": nctx,
                   "windows_ms_per_step": w_ms, "points_ms_per_step": p_ms,
                   "speedup_vs_1": {"windows": one_gpu_ms / w_ms, "points": one_gpu_ms / p_ms},
-                  "one_gpu_ms_per_step": one_gpu_ms,
+                  "one_gpu_ms_per_msm": one_gpu_ms,
                   "note": "ONE 2^logn-point MSM split over the ranks (strong scaling), timed after the weak-scaling region with the same barrier + "
                           "max-over-ranks protocol; windows = reef_msm_ctx_set_window_split(rank, N) on replicated points and scalars, points = "
-                          "contiguous slices; one_gpu_ms_per_step is the weak region's ms_per_step (a 2^logn-point MSM per GPU)"}
+                          "contiguous slices; one_gpu_ms_per_msm is the weak region's time per MSM (a 2^logn-point MSM per GPU); the *_ms_per_step figures here are per MSM"}
         strong_results = {"windows": w_res, "points": p_res}
 
     # ---- after the timed region (none of this is `value`) ------------------------------------------------
@@ -390,7 +401,7 @@ def main():
     single = None
     host_ms = None
     if not multi:
-        reps = max(3, min(10, a.steps))
+        reps = max(3, min(10, a.steps * MPS))
         for _ in range(reps):
             ctx0.msm(scalars, n, out=results[0].data_ptr())
             ctx0.sync()
@@ -408,7 +419,7 @@ def main():
             hthreads = max(nctx, 6)
             hctx = list(ctxs) + [ctxs[0].clone() for _ in range(hthreads - nctx)]
             outs = [np.zeros(12, dtype=np.uint64) for _ in hctx]
-            per_thread = max(2, min(a.steps, 24) // hthreads + 1)
+            per_thread = max(2, min(a.steps * MPS, 24) // hthreads + 1)
 
             def host_worker(j):               # one caller thread per resident-key clone, as nova's rayon workers would be
                 for _ in range(per_thread):
@@ -480,7 +491,7 @@ def main():
                     break
             except (OSError, KeyError, ValueError):
                 pass
-        pairs = n * B * (1 if by_windows else a.gpus) * a.steps
+        pairs = n * B * MPS * (1 if by_windows else a.gpus) * a.steps
         value = pairs / elapsed
         achieved = BYTES_PER_PAIR * n * B / (acc_ms * 1e-3) / 1e9 if acc_ms > 0 else None
         eff_windows = min(plan["windows"], -(-255 // plan["window_bits"]))   # windows that hold scalar bits (scalars < 2^255)
@@ -489,14 +500,14 @@ def main():
             "steps": a.steps, "warmup": a.warmup, "ms_per_step": elapsed / a.steps * 1e3, "higher_is_better": True,
             "scaling": "strong" if by_windows else "weak", "vs_baseline": None, "dtype": "u32", "data": "synthetic",
             "config": {"workload": f"2^{a.logn}-point {a.curve.capitalize()} MSM per GPU, {a.scalars} 255-bit scalars, "
-                                   f"resident key, device-resident scalars (BASELINE.json configs[1])",
+                                   f"resident key, device-resident scalars (BASELINE.json configs[1]); a step = a batch of {MPS * B} such MSMs",
                        "scalars": "device-resident (generated on the GPU before the timed region; no PCIe traffic inside it)",
-                       "host_scalars_ms_per_step": host_ms,
+                       "host_scalars_ms_per_msm": host_ms,
                        "host_scalars_note": "same MSMs with the scalars in pinned host memory and the result returned to the host, six caller "
                                             "threads each on its own clone of the resident key; PCIe-inclusive, measured after the timed region, never `value`",
                        "points_per_gpu": n, "total_points": n * (1 if by_windows else a.gpus), "window_bits": plan["window_bits"],
                        "windows": plan["windows"], "bucket_groups": plan["bucket_groups"], "tables": plan["tables"],
-                       "streams": nctx, "msms_per_step": B, "sharding": ("windows (w = rank mod N)" if by_windows else "points") if a.gpus > 1 else "none",
+                       "streams": nctx, "msms_per_step": MPS * B, "ms_per_msm": elapsed / (a.steps * MPS * B) * 1e3, "sharding": ("windows (w = rank mod N)" if by_windows else "points") if a.gpus > 1 else "none",
                        "exchange": ("none" if a.gpus == 1 else "rccl all_gather of 96 B partials + on-device add" if a.backend == "nccl"
                                     else "HOST-STAGED gloo all_gather of 96 B partials (debug fallback, not RCCL) + on-device add"),
                        "check": check, "partials_differ_from_total": partials_differ, "msm_ms_stream": tot_ms,

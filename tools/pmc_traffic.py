@@ -25,7 +25,7 @@ from collections import defaultdict
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 RND = os.environ.get("REEF_ROUND", "r02")      # file prefix: profiles are named per round
 outdir = os.path.abspath(sys.argv[1])
-bench_args = sys.argv[2:] or ["--steps", "4", "--warmup", "1", "--no-cpu-baseline", "--no-replay", "--streams", "1"]
+bench_args = sys.argv[2:] or ["--steps", "4", "--warmup", "1", "--msms-per-step", "1", "--no-cpu-baseline", "--no-replay", "--streams", "1"]
 os.makedirs(outdir, exist_ok=True)
 
 GATHER_KERNELS = ("k_accum0",)          # 64-B point gathers: FETCH_SIZE is exact (factor 1.0)

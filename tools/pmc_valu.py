@@ -21,7 +21,7 @@ for g in GROUPS:
     d = "/tmp/pmc_valu"
     subprocess.run(["rm", "-rf", d])
     cmd = ["rocprofv3", "--pmc"] + g + ["--kernel-trace", "--output-format", "csv", "-d", d, "--", sys.executable,
-           os.path.join(ROOT, "bench.py"), "--steps", "4", "--warmup", "1", "--no-cpu-baseline", "--no-replay", "--streams", "1", "--no-check"]
+           os.path.join(ROOT, "bench.py"), "--steps", "4", "--warmup", "1", "--msms-per-step", "1", "--no-cpu-baseline", "--no-replay", "--streams", "1", "--no-check"]
     p = subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, text=True, timeout=600)
     cc = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
     if p.returncode != 0 or not cc:
