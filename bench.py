@@ -329,71 +329,76 @@ def main():
     # the discrete logarithm of the whole MSM.  The weak-scaling region above stays the bench line's `value`.
     strong = None
     strong_results = {}
-    if multi and a.gpus > 1 and not by_windows:
-        from reef_amd.distributed import shard_bounds
-        cdev0 = dev if a.backend == "nccl" else "cpu"
-        ksteps = max(3, min(a.steps * MPS, 24))
+    if multi and a.gpus > 1 and not by_windows and os.environ.get("REEF_BENCH_STRONG", "1") != "0":
+        try:       # a side measurement: a failure that every rank sees alike (an exception raised before any collective) does not cost the bench line
+            from reef_amd.distributed import shard_bounds
+            cdev0 = dev if a.backend == "nccl" else "cpu"
+            ksteps = max(3, min(a.steps * MPS, 24))
 
-        def make_exch(c):
-            sc_ = None
-            if a.backend == "nccl" and stream_ordered:
-                es_ = torch.cuda.ExternalStream(c.stream, device=dev)
-                sc_ = (lambda e_: (lambda: torch.cuda.stream(e_)))(es_)
-            return PartialSumExchange((lambda c_: (lambda g, cnt, out: c_.sum_points(g.data_ptr(), cnt, out.data_ptr())))(c),
-                                      backend=a.backend, before_exchange=c.sync, stream_ctx=sc_)
+            def make_exch(c):
+                sc_ = None
+                if a.backend == "nccl" and stream_ordered:
+                    es_ = torch.cuda.ExternalStream(c.stream, device=dev)
+                    sc_ = (lambda e_: (lambda: torch.cuda.stream(e_)))(es_)
+                return PartialSumExchange((lambda c_: (lambda g, cnt, out: c_.sum_points(g.data_ptr(), cnt, out.data_ptr())))(c),
+                                          backend=a.backend, before_exchange=c.sync, stream_ctx=sc_)
 
-        def timed(cs, xs, sc_ptr, cnt):
-            def one(i):
-                j = i % len(cs)
-                cs[j].msm(sc_ptr, cnt, out=parts[j].data_ptr())
-                xs[j].combine(parts[j], gathered[j], results[j])
-            def sync_cs():
-                for c in cs:
-                    c.sync()
+            def timed(cs, xs, sc_ptr, cnt):
+                def one(i):
+                    j = i % len(cs)
+                    cs[j].msm(sc_ptr, cnt, out=parts[j].data_ptr())
+                    xs[j].combine(parts[j], gathered[j], results[j])
+                def sync_cs():
+                    for c in cs:
+                        c.sync()
+                    torch.cuda.synchronize()
+                for i in range(len(cs)):
+                    one(i)
+                sync_cs()
+                dist.barrier()
                 torch.cuda.synchronize()
-            for i in range(len(cs)):
-                one(i)
-            sync_cs()
-            dist.barrier()
-            torch.cuda.synchronize()
-            t0_ = time.perf_counter()
-            for i in range(ksteps):
-                one(i)
-            sync_cs()
-            dist.barrier()
-            torch.cuda.synchronize()
-            t_ = torch.tensor([time.perf_counter() - t0_], dtype=torch.float64, device=cdev0)
-            dist.all_reduce(t_, op=dist.ReduceOp.MAX)
-            return float(t_.item()) / ksteps * 1e3, results[(ksteps - 1) % len(cs)].cpu().numpy().copy()
+                t0_ = time.perf_counter()
+                for i in range(ksteps):
+                    one(i)
+                sync_cs()
+                dist.barrier()
+                torch.cuda.synchronize()
+                t_ = torch.tensor([time.perf_counter() - t0_], dtype=torch.float64, device=cdev0)
+                dist.all_reduce(t_, op=dist.ReduceOp.MAX)
+                return float(t_.item()) / ksteps * 1e3, results[(ksteps - 1) % len(cs)].cpu().numpy().copy()
 
-        # rank 0's points and scalars are THE MSM; the other ranks generate the same ones (seeded, on the device)
-        bases0 = bases if rank == 0 else msm.gen_bases(a.curve, k0, d, n, device=True)
-        scal0 = scalars if rank == 0 else msm.gen_scalars(a.curve, 0x5EEF, n, kind=kind, mont=True, device=True)
-        if rank == 0:
-            wfirst = ctx0.clone()
-        else:
-            wfirst = msm.MsmContext(a.curve, bases0, n, window_bits=a.window_bits, bucket_groups=groups, chunk=a.chunk)
-        wfirst.set_window_split(rank, world)
-        wctx = [wfirst] + [wfirst.clone() for _ in range(nctx - 1)]          # clones inherit the split
-        w_ms, w_res = timed(wctx, [make_exch(c) for c in wctx], scal0, n)
-        for c in wctx:
-            c.close()
-        lo, hi = shard_bounds(n, world, rank)
-        bases_s = msm.gen_bases(a.curve, k0 + lo * d, d, hi - lo, device=True)
-        pfirst = msm.MsmContext(a.curve, bases_s, hi - lo, window_bits=a.window_bits, bucket_groups=groups, chunk=a.chunk)
-        pctx = [pfirst] + [pfirst.clone() for _ in range(nctx - 1)]
-        p_ms, p_res = timed(pctx, [make_exch(c) for c in pctx], scal0.ptr + 32 * lo, hi - lo)
-        for c in pctx:
-            c.close()
-        one_gpu_ms = elapsed / (a.steps * MPS) * 1e3      # what one GPU needs for a 2^logn-point MSM in the same regime (the weak region above)
-        strong = {"one_msm_points": n, "steps": ksteps, "in_flight": nctx,
-                  "windows_ms_per_step": w_ms, "points_ms_per_step": p_ms,
-                  "speedup_vs_1": {"windows": one_gpu_ms / w_ms, "points": one_gpu_ms / p_ms},
-                  "one_gpu_ms_per_msm": one_gpu_ms,
-                  "note": "ONE 2^logn-point MSM split over the ranks (strong scaling), timed after the weak-scaling region with the same barrier + "
-                          "max-over-ranks protocol; windows = reef_msm_ctx_set_window_split(rank, N) on replicated points and scalars, points = "
-                          "contiguous slices; one_gpu_ms_per_msm is the weak region's time per MSM (a 2^logn-point MSM per GPU); the *_ms_per_step figures here are per MSM"}
-        strong_results = {"windows": w_res, "points": p_res}
+            # rank 0's points and scalars are THE MSM; the other ranks generate the same ones (seeded, on the device)
+            bases0 = bases if rank == 0 else msm.gen_bases(a.curve, k0, d, n, device=True)
+            scal0 = scalars if rank == 0 else msm.gen_scalars(a.curve, 0x5EEF, n, kind=kind, mont=True, device=True)
+            if rank == 0:
+                wfirst = ctx0.clone()
+            else:
+                wfirst = msm.MsmContext(a.curve, bases0, n, window_bits=a.window_bits, bucket_groups=groups, chunk=a.chunk)
+            wfirst.set_window_split(rank, world)
+            wctx = [wfirst] + [wfirst.clone() for _ in range(nctx - 1)]          # clones inherit the split
+            w_ms, w_res = timed(wctx, [make_exch(c) for c in wctx], scal0, n)
+            for c in wctx:
+                c.close()
+            lo, hi = shard_bounds(n, world, rank)
+            bases_s = msm.gen_bases(a.curve, k0 + lo * d, d, hi - lo, device=True)
+            pfirst = msm.MsmContext(a.curve, bases_s, hi - lo, window_bits=a.window_bits, bucket_groups=groups, chunk=a.chunk)
+            pctx = [pfirst] + [pfirst.clone() for _ in range(nctx - 1)]
+            p_ms, p_res = timed(pctx, [make_exch(c) for c in pctx], scal0.ptr + 32 * lo, hi - lo)
+            for c in pctx:
+                c.close()
+            one_gpu_ms = elapsed / (a.steps * MPS) * 1e3      # what one GPU needs for a 2^logn-point MSM in the same regime (the weak region above)
+            strong = {"one_msm_points": n, "steps": ksteps, "in_flight": nctx,
+                      "windows_ms_per_step": w_ms, "points_ms_per_step": p_ms,
+                      "speedup_vs_1": {"windows": one_gpu_ms / w_ms, "points": one_gpu_ms / p_ms},
+                      "one_gpu_ms_per_msm": one_gpu_ms,
+                      "note": "ONE 2^logn-point MSM split over the ranks (strong scaling), timed after the weak-scaling region with the same barrier + "
+                              "max-over-ranks protocol; windows = reef_msm_ctx_set_window_split(rank, N) on replicated points and scalars, points = "
+                              "contiguous slices; one_gpu_ms_per_msm is the weak region's time per MSM (a 2^logn-point MSM per GPU); the *_ms_per_step figures here are per MSM"}
+            strong_results = {"windows": w_res, "points": p_res}
+
+        except Exception as e:
+            print(f"[bench] strong-scaling legs failed on rank {rank}: {e}", file=sys.stderr)
+            strong, strong_results = {"error": str(e)}, {}
 
     # ---- after the timed region (none of this is `value`) ------------------------------------------------
     # (1) the accumulation kernel with ONE MSM in flight: with several MSMs sharing the chip a launch is stretched by
