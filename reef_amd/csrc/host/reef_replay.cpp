@@ -32,6 +32,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <memory>
 #include <stdexcept>
 #include <string>
 #include <vector>
@@ -46,6 +47,20 @@
         reef_status s_ = (x);                                                              \
         if (s_ != REEF_OK) fail(std::string(#x) + " failed: " + reef_last_error());        \
     } while (0)
+
+// Everything the replay allocates is owned by one of these: a failed call (an exception) unwinds through them, so a replay that
+// ends early inside bench.py's process leaves no key and no device buffer behind.
+struct DevFree { void operator()(void *p) const { if (p) reef_device_free(p); } };
+template <class T> using dev_ptr = std::unique_ptr<T, DevFree>;
+struct CtxFree { void operator()(reef_msm_ctx *p) const { if (p) reef_msm_ctx_destroy(p); } };
+using ctx_ptr = std::unique_ptr<reef_msm_ctx, CtxFree>;
+struct ScFree { void operator()(reef_sc_ctx *p) const { if (p) reef_sc_destroy(p); } };
+using sc_ptr = std::unique_ptr<reef_sc_ctx, ScFree>;
+template <class T> static dev_ptr<T> device_alloc(size_t count) {
+    T *p = (T *)reef_device_alloc(count * sizeof(T));
+    if (!p) throw std::runtime_error(std::string("alloc: ") + reef_last_error());
+    return dev_ptr<T>(p);
+}
 
 using clk = std::chrono::steady_clock;
 static double ms_since(clk::time_point t0) { return std::chrono::duration<double, std::milli>(clk::now() - t0).count(); }
@@ -185,10 +200,9 @@ static void check_point(Curve &c, const reef_jacobian &got, const reef_fe &dlog,
 
 static size_t next_pow2(size_t x) { size_t p = 1; while (p < x) p <<= 1; return p; }
 
-static reef_fe *device_scalars(int curve, uint64_t seed, int kind, size_t n) {
-    reef_fe *p = (reef_fe *)reef_device_alloc(n * sizeof(reef_fe));
-    if (!p) fail(std::string("alloc: ") + reef_last_error());
-    CK(reef_gen_scalars(curve, seed, kind, 0, n, true, p, REEF_DEVICE));
+static dev_ptr<reef_fe> device_scalars(int curve, uint64_t seed, int kind, size_t n) {
+    dev_ptr<reef_fe> p = device_alloc<reef_fe>(n);
+    CK(reef_gen_scalars(curve, seed, kind, 0, n, true, p.get(), REEF_DEVICE));
     return p;
 }
 
@@ -215,8 +229,7 @@ static double run_ipa_nofold(Curve &c, size_t n, const reef_fe *d_scalars, int *
 static double run_ipa(Curve &c, size_t n, const reef_fe *d_scalars, int *rounds_out) {
     auto t0 = clk::now();
     reef_affine *cur = c.d_gens;
-    reef_affine *buf[2] = {(reef_affine *)reef_device_alloc(n / 2 * sizeof(reef_affine) + 64),
-                           (reef_affine *)reef_device_alloc(n / 2 * sizeof(reef_affine) + 64)};
+    dev_ptr<reef_affine> buf[2] = {device_alloc<reef_affine>(n / 2 + 1), device_alloc<reef_affine>(n / 2 + 1)};
     reef_jacobian L, R;
     reef_fe w1 = {{0x1234567890abcdefULL, 0x0fedcba987654321ULL, 0x1111111122222222ULL, 0x0333333344444444ULL}};
     reef_fe w2 = {{0x0badc0ffee0ddf00ULL, 0x0123456789abcdefULL, 0x5555555566666666ULL, 0x0777777788888888ULL}};
@@ -229,12 +242,10 @@ static double run_ipa(Curve &c, size_t n, const reef_fe *d_scalars, int *rounds_
         // pre-shifted tables the library then finishes the window combine on a host core
         CK(reef_msm(c.ipa[0], d_scalars, half, REEF_DEVICE, true, &L, REEF_HOST));
         CK(reef_msm(c.ipa[1], d_scalars + half, half, REEF_DEVICE, true, &R, REEF_HOST));
-        CK(reef_fold(c.id, cur, half, REEF_DEVICE, &w1, &w2, buf[flip]));   // G' = w1*G_lo + w2*G_hi
-        cur = buf[flip];
+        CK(reef_fold(c.id, cur, half, REEF_DEVICE, &w1, &w2, buf[flip].get()));   // G' = w1*G_lo + w2*G_hi
+        cur = buf[flip].get();
         flip ^= 1;
     }
-    reef_device_free(buf[0]);
-    reef_device_free(buf[1]);
     if (rounds_out) *rounds_out = rounds;
     return ms_since(t0);
 }
@@ -244,7 +255,7 @@ static double run_ipa(Curve &c, size_t n, const reef_fe *d_scalars, int *rounds_
 // per step: the nlookup sum-check of witness generation (r1cs.rs:2318-2385) as reef_sc_* rounds, the
 //           Poseidon challenge of every round replaced by a fixed field element (it stays on the host).
 // proof end: doc_poly.evaluate / the row binding of prove_eval (commitment.rs:357,371-391).
-static uint8_t *device_symbols(size_t n, int bits, uint64_t seed) {
+static dev_ptr<uint8_t> device_symbols(size_t n, int bits, uint64_t seed) {
     std::vector<uint8_t> h(n);
     uint64_t x = seed;
     const uint32_t bound = bits >= 8 ? 131u : (bits == 3 ? 7u : (1u << bits));
@@ -252,9 +263,8 @@ static uint8_t *device_symbols(size_t n, int bits, uint64_t seed) {
         x = x * 6364136223846793005ULL + 1442695040888963407ULL;
         h[i] = (uint8_t)((x >> 33) % bound);
     }
-    uint8_t *d = (uint8_t *)reef_device_alloc(n);
-    if (!d) fail(std::string("alloc: ") + reef_last_error());
-    CK(reef_memcpy(d, h.data(), n, REEF_DEVICE, REEF_HOST));
+    dev_ptr<uint8_t> d = device_alloc<uint8_t>(n);
+    CK(reef_memcpy(d.get(), h.data(), n, REEF_DEVICE, REEF_HOST));
     return d;
 }
 
@@ -262,7 +272,9 @@ static double run_hyrax_commit(const Shape *sh, reef_affine *d_gens, const uint8
     const size_t rows = (size_t)1 << (sh->doc_log / 2), row_len = (size_t)1 << (sh->doc_log - sh->doc_log / 2);
     reef_msm_ctx *key = nullptr;
     CK(reef_msm_ctx_create(&key, REEF_PALLAS, d_gens, row_len, REEF_DEVICE, nullptr));
-    reef_jacobian *d_out = (reef_jacobian *)reef_device_alloc(rows * sizeof(reef_jacobian));
+    const ctx_ptr key_owner(key);
+    const dev_ptr<reef_jacobian> d_out_owner = device_alloc<reef_jacobian>(rows);
+    reef_jacobian *d_out = d_out_owner.get();
     auto t0 = clk::now();
     CK(reef_msm_rows_symbols(key, d_doc, rows, row_len, REEF_DEVICE, (uint32_t)sh->symbol_bits, nullptr, nullptr, true, d_out, REEF_DEVICE));
     CK(reef_msm_ctx_sync(key));
@@ -271,8 +283,6 @@ static double run_hyrax_commit(const Shape *sh, reef_affine *d_gens, const uint8
     CK(reef_msm_rows_symbols(key, d_doc, rows, row_len, REEF_DEVICE, (uint32_t)sh->symbol_bits, nullptr, nullptr, true, d_out, REEF_DEVICE));
     CK(reef_msm_ctx_sync(key));
     const double again = ms_since(t0);
-    reef_device_free(d_out);
-    reef_msm_ctx_destroy(key);
     return again;
 }
 
@@ -305,9 +315,12 @@ static std::string replay_body(const Shape &shape, bool nofold, bool tables, con
     cv[0].id = REEF_PALLAS; cv[0].n = next_pow2(sh->w1 > sh->c1 ? sh->w1 : sh->c1);
     cv[1].id = REEF_VESTA;  cv[1].n = next_pow2(sh->w2 > sh->c2 ? sh->w2 : sh->c2);
 
+    std::vector<dev_ptr<reef_affine>> owned_gens;       // destroyed after the contexts below
+    std::vector<ctx_ptr> owned_ctx;
     auto t_setup = clk::now();
     for (Curve &c : cv) {
-        c.d_gens = (reef_affine *)reef_device_alloc(c.n * sizeof(reef_affine));
+        owned_gens.push_back(device_alloc<reef_affine>(c.n));
+        c.d_gens = owned_gens.back().get();
         auto t0 = clk::now();
         c.k0 = 0xC0FFEE + c.id; c.d = 7;
         CK(reef_gen_bases(c.id, c.k0, c.d, c.n, c.d_gens, REEF_DEVICE));
@@ -319,6 +332,7 @@ static std::string replay_body(const Shape &shape, bool nofold, bool tables, con
             og.bucket_groups = 1;
             og.device = -1;
             CK(reef_msm_ctx_create(&c.one, c.id, &g1, 1, REEF_HOST, &og));
+            owned_ctx.emplace_back(c.one);
         }
         reef_msm_opts o = {};
         o.bucket_groups = 1;  // commitment keys are fixed for the life of PublicParams: pre-shift once
@@ -326,13 +340,14 @@ static std::string replay_body(const Shape &shape, bool nofold, bool tables, con
         o.device = -1;
         t0 = clk::now();
         CK(reef_msm_ctx_create(&c.key, c.id, c.d_gens, c.n, REEF_DEVICE, &o));
+        owned_ctx.emplace_back(c.key);
         CK(reef_msm_ctx_sync(c.key));
         const double key_ms = ms_since(t0);
         reef_msm_opts plain = {};
         plain.device = -1;
         t0 = clk::now();
         if (!nofold)   // the per-round re-keyed contexts exist only in the generator-fold IPA
-            for (auto &x : c.ipa) CK(reef_msm_ctx_create(&x, c.id, c.d_gens, c.n / 2, REEF_DEVICE, &plain));
+            for (auto &x : c.ipa) { CK(reef_msm_ctx_create(&x, c.id, c.d_gens, c.n / 2, REEF_DEVICE, &plain)); owned_ctx.emplace_back(x); }
         if (getenv("REEF_REPLAY_VERBOSE"))
             fprintf(stderr, "setup curve %d: synthetic generators %.2f ms, resident pre-shifted key (%zu points) %.2f ms, plain IPA keys %.2f ms\n",
                     c.id, gen_ms, c.n, key_ms, ms_since(t0));
@@ -340,8 +355,9 @@ static std::string replay_body(const Shape &shape, bool nofold, bool tables, con
     const double setup_ms = ms_since(t_setup);
 
     // witness-like scalars for W, uniform for the cross terms T
-    reef_fe *sW1 = device_scalars(REEF_PALLAS, 11, 1, cv[0].n), *sT1 = device_scalars(REEF_PALLAS, 12, 0, cv[0].n);
-    reef_fe *sW2 = device_scalars(REEF_VESTA, 13, 1, cv[1].n), *sT2 = device_scalars(REEF_VESTA, 14, 0, cv[1].n);
+    const dev_ptr<reef_fe> oW1 = device_scalars(REEF_PALLAS, 11, 1, cv[0].n), oT1 = device_scalars(REEF_PALLAS, 12, 0, cv[0].n);
+    const dev_ptr<reef_fe> oW2 = device_scalars(REEF_VESTA, 13, 1, cv[1].n), oT2 = device_scalars(REEF_VESTA, 14, 0, cv[1].n);
+    reef_fe *sW1 = oW1.get(), *sT1 = oT1.get(), *sW2 = oW2.get(), *sT2 = oT2.get();
     // the same vectors in HOST memory (Montgomery form, what nova holds) and as canonical integers (for the check)
     struct HostVec { std::vector<reef_fe> mont, canon; };
     auto host_vec = [&](int curve, uint64_t seed, int kind, size_t n) {
@@ -434,10 +450,10 @@ static std::string replay_body(const Shape &shape, bool nofold, bool tables, con
             o.byte_tables = tables ? 1 : 2;
             o.device = -1;
             CK(reef_msm_ctx_create(&hy.key, hy.id, hy.d_gens, hy.n, REEF_DEVICE, &o));
+            const ctx_ptr hy_owner(hy.key);
             reef_jacobian warm_l, warm_r;
             CK(reef_ipa_cross_terms(hy.key, sT1, hy.n, REEF_DEVICE, true, nullptr, nullptr, 0, &warm_l, &warm_r));
             cons_ms = run_ipa_nofold(hy, hy.n, sT1, &r3);
-            reef_msm_ctx_destroy(hy.key);
         } else {
             cons_ms = run_ipa(hy, hy.n, sT1, &r3);
         }
@@ -447,9 +463,11 @@ static std::string replay_body(const Shape &shape, bool nofold, bool tables, con
     double commit_ms = 0, commit_first_ms = 0, sc_step_ms = 0, mle_ms = 0;
     if (sh->doc_log) {
         const size_t n_doc = (size_t)1 << sh->doc_log;
-        uint8_t *d_doc = device_symbols(n_doc, sh->symbol_bits, 0xD0C);
+        const dev_ptr<uint8_t> doc_owner = device_symbols(n_doc, sh->symbol_bits, 0xD0C);
+        uint8_t *d_doc = doc_owner.get();
         const size_t row_len = (size_t)1 << (sh->doc_log - sh->doc_log / 2);
-        reef_affine *d_row_gens = (reef_affine *)reef_device_alloc(row_len * sizeof(reef_affine));
+        const dev_ptr<reef_affine> row_gens_owner = device_alloc<reef_affine>(row_len);
+        reef_affine *d_row_gens = row_gens_owner.get();
         CK(reef_gen_bases(REEF_PALLAS, 0xFEED, 3, row_len, d_row_gens, REEF_DEVICE));
         commit_ms = run_hyrax_commit(sh, d_row_gens, d_doc, &commit_first_ms);
         std::vector<reef_fe> point(sh->doc_log);
@@ -460,20 +478,19 @@ static std::string replay_body(const Shape &shape, bool nofold, bool tables, con
         auto t0 = clk::now();
         CK(reef_mle_bound_rows(REEF_PALLAS, d_doc, n_doc, 1, REEF_DEVICE, true, point.data(), sh->doc_log, sh->doc_log / 2, lz.data(), REEF_HOST, &ev));
         mle_ms = ms_since(t0);
-        reef_device_free(d_row_gens);
-        reef_device_free(d_doc);
     }
     if (sh->table_log) {
         const size_t len = (size_t)1 << sh->table_log;
         reef_sc_ctx *sc = nullptr;
         CK(reef_sc_create(&sc, REEF_PALLAS, len));
-        reef_fe *d_tab = (reef_fe *)reef_device_alloc(len * sizeof(reef_fe));
+        const sc_ptr sc_owner(sc);
+        dev_ptr<reef_fe> tab_owner = device_alloc<reef_fe>(len);
+        reef_fe *d_tab = tab_owner.get();
         CK(reef_gen_scalars(REEF_PALLAS, 0x7AB1E, 2, 1u << 20, len, false, d_tab, REEF_DEVICE));   // packed lookup values, canonical
         CK(reef_sc_set_table(sc, 0, d_tab, len, REEF_DEVICE));
-        reef_device_free(d_tab);
+        tab_owner.reset();
         run_sumcheck_step(sc, sh->table_log, sh->lookups);            // warm-up
         sc_step_ms = run_sumcheck_step(sc, sh->table_log, sh->lookups);
-        reef_sc_destroy(sc);
     }
 
     // ---- rows N1 and N4 with STAND-IN parameters (replay_standins.h): the keys derived from a label on the GPU, and for
@@ -486,12 +503,12 @@ static std::string replay_body(const Shape &shape, bool nofold, bool tables, con
         kp.a = sp[0]; kp.b = sp[1]; kp.z = sp[2];
         memcpy(kp.iso, sp + 3, 13 * sizeof(reef_fe));
         kp.dst = (const uint8_t *)dst; kp.dst_len = (uint32_t)strlen(dst); kp.little_endian = 0;
-        reef_affine *d_key = (reef_affine *)reef_device_alloc(c.n * sizeof(reef_affine));
+        const dev_ptr<reef_affine> key_owner = device_alloc<reef_affine>(c.n);
+        reef_affine *d_key = key_owner.get();
         CK(reef_derive_generators(c.id, (const uint8_t *)"ck", 2, c.n, &kp, false, d_key, REEF_DEVICE));   // warm-up
         auto t0 = clk::now();
         CK(reef_derive_generators(c.id, (const uint8_t *)"ck", 2, c.n, &kp, false, d_key, REEF_DEVICE));
         derive_ms += ms_since(t0);
-        reef_device_free(d_key);
     }
     if (sh->merkle_log) {
         const size_t n_doc = (size_t)1 << sh->merkle_log;
@@ -523,14 +540,7 @@ static std::string replay_body(const Shape &shape, bool nofold, bool tables, con
            cons_ms, r3, steps_ms + final_ms + cons_ms, commit_ms, commit_first_ms, sh->table_log, sc_step_ms, mle_ms,
            steps_ms + final_ms + cons_ms + sh->steps * sc_step_ms + mle_ms, derive_ms, sh->merkle_log, merkle_ms,
            tables ? "\"built with the keys (inside setup_ms): MSMs of 1025..65536 points are sums of table entries\"" : "\"none (bucket pipeline)\"");
-    for (Curve &c : cv) {
-        reef_msm_ctx_destroy(c.key);
-        reef_msm_ctx_destroy(c.one);
-        for (auto &x : c.ipa) reef_msm_ctx_destroy(x);
-        reef_device_free(c.d_gens);
-    }
-    reef_device_free(sW1); reef_device_free(sT1); reef_device_free(sW2); reef_device_free(sT2);
-    return std::string(line.data());
+    return std::string(line.data());        // the owners above release every context and device buffer, here or on an exception
 }
 
 // ---- entry points ---------------------------------------------------------------------------------------------------
