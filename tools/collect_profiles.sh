@@ -47,3 +47,4 @@ bash $root/tools/batch_sweep.sh $out/${R}_batch_sweep.txt > /dev/null 2>&1
  for m in 2048 8192 16384 32768 65536; do echo "## N = $m"; REEF_POSEIDON_SPREAD_MAX=$m python $root/tools/time_merkle.py 10 14 16 18 20 22 | grep symbols; done
  echo "## a thread per node"; REEF_POSEIDON_SPREAD=0 python $root/tools/time_merkle.py 10 14 16 18 20 22 | grep symbols) > $out/${R}_merkle_spread.txt 2>&1
 (for f in 1 0; do echo "REEF_MSM_FUSE_MERGE=$f"; REEF_MSM_FUSE_MERGE=$f python $root/tools/sweep_plans.py 12 14 15 16 17 2>&1 | grep "##" | grep "G=1"; done) > $out/${R}_fused_merge_ab.txt 2>&1
+python $root/tools/pmc_streaming.py $out/${R}_pmc_streaming.json > /dev/null 2>&1
