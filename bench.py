@@ -157,6 +157,42 @@ def cpu_baseline(curve_id, seconds):
                       f"{threads} threads on {cores} visible host cores (the container's CPU quota is {quota if quota else 'none'}: best of quota/2, quota, 2 x quota threads -- or of all, 1/2, 1/4 of the cores without one; speed-up over one thread {value / one_thread_rate:.1f}x)"}
 
 
+def hbm_bound_leg(ell=26):
+    """After the timed region, never `value`: the HBM-bound row of the same path under the driver's clock -- one fused round of the
+    nlookup sum-check (row N2: fold both tables with the previous challenge and sum the next round's coefficients in ONE pass,
+    src/backend/r1cs_helper.rs:441-506) over tables of 2^ell field elements, its algorithmic bytes against the HBM peak, and the
+    sum-check identity of the round as the check (g(0) + g(1) of a round equals the claim the previous challenge leaves)."""
+    from oracle.sumcheck_oracle import Q
+    from reef_amd import msm
+    from reef_amd.sumcheck import SumCheck
+    n = 1 << ell
+    doc = msm.gen_scalars("pallas", 0xD0C, n, kind=2, small_bound=1 << 20, mont=False, device=True)
+    eqv = msm.gen_scalars("pallas", 0xE9, n, kind=0, mont=False, device=True)
+    with SumCheck("pallas", ell) as sc:
+        best = None
+        ok = True
+        for rep in range(3):
+            sc.set_table_device(0, doc.ptr, n)
+            sc.set_table_device(1, eqv.ptr, n)
+            sc.sync()
+            xsq, x, con = sc.round_coeffs(1)
+            r = (xsq * 7 + 3) % Q
+            claim = (xsq * r * r + x * r + con) % Q          # g_1(r): what round 2 must sum to
+            t0 = time.perf_counter()
+            xsq2, x2, con2 = sc.fold_and_next_coeffs(1, r)   # returns after the pass (the coefficients come back to the host)
+            dt = time.perf_counter() - t0
+            ok = ok and (con2 + (xsq2 + x2 + con2)) % Q == claim   # g_2(0) + g_2(1)
+            best = dt if best is None or dt < best else best
+    doc.free()
+    eqv.free()
+    algo = 2 * n * 32 + 2 * (n // 2) * 32                    # both tables read once, half of each written
+    return {"kernel": "k_sc_fold_coeffs (fused sum-check round, row N2)", "table_entries": n, "entry_bytes": 32, "round_ms": best * 1e3,
+            "algorithmic_bytes": algo, "achieved": algo / best / 1e9, "unit": "GB/s", "peak": HBM_PEAK_GBS, "frac": algo / best / 1e9 / HBM_PEAK_GBS,
+            "bound": "hbm", "check": "sumcheck-identity-ok" if ok else "MISMATCH",
+            "note": "host-timed call (launch, pass, 96-byte read-back included); PMC traffic of this kernel equals its algorithmic bytes "
+                    "(profiles/r03_pmc_streaming.json)"}
+
+
 def replay_leg(cpu_seconds_ok=True, cpu_threads=None):
     """After the timed region, never `value`: the MSM sequence of one `reef --prove` on BASELINE.json configs[2]
     (src/backend/framework.rs:664-723) issued in-process through the C ABI by the C++ harness (per-step scalars in host
@@ -536,6 +572,10 @@ def main():
         if a.gpus == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(msm.curve_id(a.curve), a.cpu_seconds)
         if a.gpus == 1 and not multi and not a.no_replay:
+            try:                           # the HBM-bound row of the path (N2) beside the issue-bound headline kernel
+                out["roofline"]["hbm_bound_row"] = hbm_bound_leg()
+            except Exception as e:
+                out["roofline"]["hbm_bound_row"] = {"error": str(e)}
             try:
                 out["config"]["replay_cfg3"] = replay_leg(cpu_seconds_ok=not a.no_cpu_baseline,
                                                           cpu_threads=out.get("cpu_baseline", {}).get("cores"))
