@@ -193,10 +193,11 @@ def hbm_bound_leg(ell=26):
                     "(profiles/r03_pmc_streaming.json)"}
 
 
-def replay_leg(cpu_seconds_ok=True, cpu_threads=None):
+def replay_leg():
     """After the timed region, never `value`: the MSM sequence of one `reef --prove` on BASELINE.json configs[2]
     (src/backend/framework.rs:664-723) issued in-process through the C ABI by the C++ harness (per-step scalars in host
-    memory, commitments back to the host, every one checked), and the same sequence on the host cores through the oracle."""
+    memory, commitments back to the host, every one checked).  Runs BEFORE the CPU baseline: the sequence is bound by
+    host latency, and a container that has just burnt its CPU quota on the oracle's threads is throttled."""
     from reef_amd import replay
     out = {}
     g = replay.run("cfg3", nofold=True, tables=False)
@@ -214,12 +215,16 @@ def replay_leg(cpu_seconds_ok=True, cpu_threads=None):
                               "commitments_checked_against_dlog": t["commitments_checked_against_dlog"]}
     except Exception as e:
         out["byte_tables"] = {"error": str(e)}
-    if cpu_seconds_ok:
-        from oracle import replay_cpu
-        c = replay_cpu.run("cfg3", replay.SHAPES_PATH, cpu_threads or os.cpu_count() or 1)
-        out.update({"cpu_restatement_ms": c["total_prove_msm_ms"], "cpu_fold_ms_per_step": c["ms_per_step"],
-                    "cpu_ipa_ms": c["ipa_pallas_ms"] + c["ipa_vesta_ms"], "cores": c["threads"], "cpu_kind": c["kind"]})
     return out
+
+
+def replay_cpu_leg(out, cpu_threads=None):
+    """The same sequence on the host cores through the oracle (test infrastructure used as the reported CPU side)."""
+    from reef_amd import replay
+    from oracle import replay_cpu
+    c = replay_cpu.run("cfg3", replay.SHAPES_PATH, cpu_threads or os.cpu_count() or 1)
+    out.update({"cpu_restatement_ms": c["total_prove_msm_ms"], "cpu_fold_ms_per_step": c["ms_per_step"],
+                "cpu_ipa_ms": c["ipa_pallas_ms"] + c["ipa_vesta_ms"], "cores": c["threads"], "cpu_kind": c["kind"]})
 
 
 def main():
@@ -572,7 +577,9 @@ def main():
                 prof = json.load(open(os.path.join(ROOT, "profiles", prof_name)))
                 pc = prof["config"]
                 if (pc["curve"], pc["logn"], pc["window_bits"], pc["bucket_groups"]) == (a.curve, a.logn, plan["window_bits"], plan["bucket_groups"]):
-                    traffic = prof["kernels"]["k_accum0<0>"]["hbm_bytes_per_launch"]
+                    # the kernel's template arguments changed between rounds (r03 added the fused-merge flag)
+                    accum = [v for k, v in prof["kernels"].items() if k.startswith(f"k_accum0<{msm.curve_id(a.curve)}")]
+                    traffic = max(v["hbm_bytes_per_launch"] for v in accum)
                     traffic_src = f"profiles/{prof_name} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes)"
                     break
             except (OSError, KeyError, ValueError):
@@ -614,18 +621,23 @@ def main():
                          "issue": {"field_products_per_s": value / a.gpus * eff_windows * 10, "peak": FMUL_PEAK,
                                    "frac": value / a.gpus * eff_windows * 10 / FMUL_PEAK, "unit": "products/s"}},
         }
-        if a.gpus == 1 and not a.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(msm.curve_id(a.curve), a.cpu_seconds)
-        if a.gpus == 1 and not multi and not a.no_replay:
+        side_legs = a.gpus == 1 and not multi and not a.no_replay
+        if side_legs:                      # GPU side legs first: they are host-latency sensitive (see replay_leg)
             try:                           # the HBM-bound row of the path (N2) beside the issue-bound headline kernel
                 out["roofline"]["hbm_bound_row"] = hbm_bound_leg()
             except Exception as e:
                 out["roofline"]["hbm_bound_row"] = {"error": str(e)}
             try:
-                out["config"]["replay_cfg3"] = replay_leg(cpu_seconds_ok=not a.no_cpu_baseline,
-                                                          cpu_threads=out.get("cpu_baseline", {}).get("cores"))
+                out["config"]["replay_cfg3"] = replay_leg()
             except Exception as e:         # a side measurement never takes the bench line down
                 out["config"]["replay_cfg3"] = {"error": str(e)}
+        if a.gpus == 1 and not a.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(msm.curve_id(a.curve), a.cpu_seconds)
+            if side_legs and "error" not in out["config"]["replay_cfg3"]:
+                try:
+                    replay_cpu_leg(out["config"]["replay_cfg3"], cpu_threads=out["cpu_baseline"].get("cores"))
+                except Exception as e:
+                    out["config"]["replay_cfg3"]["cpu_error"] = str(e)
         os.write(json_fd, (json.dumps(out) + "\n").encode())
     if multi:
         dist.barrier()
