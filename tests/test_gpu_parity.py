@@ -136,6 +136,57 @@ def test_golden_seeded(golden, gpu_lib):
 
 
 @pytest.mark.parametrize("name", ["pallas", "vesta"])
+def test_device_resident_blinding_generator(name, gpu_lib, cref):
+    """CE::commit / HyraxPC::commit with every buffer on the device (commitment.rs:187, :349-351): the table of h follows a
+    device-resident h WITHOUT a host round trip (k_h_refresh) -- rewritten in place, the identity, and mixed with calls
+    that pass h from the host."""
+    from reef_amd import msm
+    from reef_amd import _ffi
+    cid = msm.curve_id(name)
+    rows, row_len = 37, 700
+    bases = cref.gen_bases_ap(cid, 0xD0C, 3, row_len)
+    sc = cref.gen_scalars(cid, 31, rows * row_len)
+    bl = cref.gen_scalars(cid, 32, rows)
+    hs = [cref.gen_bases_ap(cid, 0xB11D + k, 1 + k, 1)[0].copy() for k in range(3)]
+    hs.append(np.zeros_like(hs[0]))                      # the identity (0, 0): the blind term vanishes
+    want = [cref.compress(cid, cref.row_msm(cid, bases, sc, rows, row_len, h=h, blinds=bl, threads=4)) for h in hs]
+    d_sc, d_bl, d_h = msm.DeviceBuffer.from_host(sc), msm.DeviceBuffer.from_host(bl), msm.DeviceBuffer.from_host(hs[0])
+    out = msm.DeviceBuffer(96 * rows)
+
+    def put(h):
+        h = np.ascontiguousarray(h)
+        msm.check(_ffi.load().reef_memcpy(d_h.ptr, h.ctypes.data, h.nbytes, msm.REEF_DEVICE, msm.REEF_HOST))
+
+    def run_device(ctx):
+        ctx.msm_rows(d_sc, rows, row_len, blinds=d_bl, h=d_h, out=out)
+        ctx.sync()
+        return msm.compress(cid, out.to_host((rows, 12)))
+
+    with msm.MsmContext(name, bases) as ctx:
+        for rep in range(2):                             # the second pass meets a table built for the last h of the first
+            for k in (0, 0, 1, 3, 2, 2, 0):
+                put(hs[k])
+                assert run_device(ctx) == want[k], (rep, k)
+            # h from the host in between: each path must see that the other one rebuilt the table
+            assert msm.compress(cid, ctx.msm_rows(sc, rows, row_len, blinds=bl, h=hs[1])) == want[1]
+            put(hs[0])
+            assert run_device(ctx) == want[0]
+            assert msm.compress(cid, ctx.msm_rows(sc, rows, row_len, blinds=bl, h=hs[1])) == want[1]
+            put(hs[1])
+            assert run_device(ctx) == want[1]
+        # one short commitment (the nibble-table path takes h's table as its second segment)
+        v = cref.gen_scalars(cid, 33, 300)
+        b1 = cref.gen_scalars(cid, 34, 1)
+        d_v, d_b1 = msm.DeviceBuffer.from_host(v), msm.DeviceBuffer.from_host(b1)
+        one = msm.DeviceBuffer(96)
+        for k in (2, 0):
+            put(hs[k])
+            ctx.msm_rows(d_v, 1, 300, blinds=d_b1, h=d_h, out=one)
+            ctx.sync()
+            assert msm.compress(cid, one.to_host((1, 12))) == cref.compress(cid, cref.row_msm(cid, bases, v, 1, 300, h=hs[k], blinds=b1, threads=2))
+
+
+@pytest.mark.parametrize("name", ["pallas", "vesta"])
 @pytest.mark.parametrize("plan", [(0, 0), (7, 0), (7, 1), (9, 3), (12, 1), (13, 0), (16, 0), (4, 2)])
 def test_plans_vs_c_oracle(name, plan, gpu_lib, cref):
     """Every (window, bucket-group) plan gives the oracle's answer; prefix MSMs (n < key length)."""
