@@ -174,6 +174,19 @@ def test_device_resident_blinding_generator(name, gpu_lib, cref):
             assert msm.compress(cid, ctx.msm_rows(sc, rows, row_len, blinds=bl, h=hs[1])) == want[1]
             put(hs[1])
             assert run_device(ctx) == want[1]
+        # blinds on the edges of the nibble decomposition (canonical form): 0, 1, r - 1, every nibble 1 / 8 / 15
+        r_ = CURVES[name].order
+        edge = [0, 1, r_ - 1, int("1" * 63, 16), int("8" * 63, 16) % r_, int("f" * 64, 16) % r_, 15 << 252 if (15 << 252) < r_ else 3 << 252]
+        e_sc = cref.gen_scalars(cid, 35, len(edge) * row_len, mont=False)
+        e_bl = np.array([[(b >> (64 * i)) & 0xFFFFFFFFFFFFFFFF for i in range(4)] for b in edge], dtype=np.uint64)
+        e_want = cref.compress(cid, cref.row_msm(cid, bases, e_sc, len(edge), row_len, h=hs[2], blinds=e_bl, mont=False, threads=2))
+        d_esc, d_ebl = msm.DeviceBuffer.from_host(e_sc), msm.DeviceBuffer.from_host(e_bl)
+        e_out = msm.DeviceBuffer(96 * len(edge))
+        put(hs[2])
+        ctx.msm_rows(d_esc, len(edge), row_len, is_mont=False, blinds=d_ebl, h=d_h, out=e_out)
+        ctx.sync()
+        assert msm.compress(cid, e_out.to_host((len(edge), 12))) == e_want
+        assert msm.compress(cid, ctx.msm_rows(e_sc, len(edge), row_len, is_mont=False, blinds=e_bl, h=hs[2])) == e_want
         # one short commitment (the nibble-table path takes h's table as its second segment)
         v = cref.gen_scalars(cid, 33, 300)
         b1 = cref.gen_scalars(cid, 34, 1)
