@@ -146,5 +146,15 @@ while time.time() < t_end:
                 sym = np.ascontiguousarray(R.gen_scalars(cid, seed, rows * row_len, kind=2, small_bound=bound, mont=False)[:, 0].astype(np.uint8))
                 bits = max(1, (bound - 1).bit_length())
                 assert msm.compress(cid, ctx.msm_rows_symbols(sym, rows, row_len, bits, blinds=bl, h=h)) == want, ("sym", cid, rows, row_len, bound)
+            if rng.random() < 0.5:      # every buffer on the device, another h (its table is checked and rebuilt on the device)
+                h2 = R.gen_bases_ap(cid, int(rng.integers(1, 1 << 30)), 1, 1)[0].copy() if rng.random() < 0.8 else np.zeros_like(h)
+                want2 = R.compress(cid, R.row_msm(cid, bases, sc, rows, row_len, h=h2, blinds=bl, threads=16))
+                d_sc, d_bl, d_h, d_out = (msm.DeviceBuffer.from_host(sc), msm.DeviceBuffer.from_host(bl), msm.DeviceBuffer.from_host(h2),
+                                          msm.DeviceBuffer(96 * rows))
+                for _ in range(2):
+                    ctx.msm_rows(d_sc, rows, row_len, blinds=d_bl, h=d_h, out=d_out)
+                    ctx.sync()
+                    assert msm.compress(cid, d_out.to_host((rows, 12))) == want2, ("rows-device", cid, rows, row_len, bound)
+                assert msm.compress(cid, ctx.msm_rows(sc, rows, row_len, blinds=bl, h=h)) == want, ("rows-host-again", cid, rows, row_len)
     done += 1
 print(f"soak ok: {done} random cases in {budget:.0f} s")
