@@ -168,3 +168,92 @@ def test_fused_fold_and_next_coeffs(gpu_lib):
             else:
                 sc.fold(i, r)
         assert sc.read(0, 1) == [t[0]] and sc.read(1, 1) == [e[0]]
+
+
+@pytest.mark.parametrize("curve,ell,n_t,nq,fused", [("pallas", 2, 3, 1, False), ("pallas", 3, 8, 3, True), ("pallas", 7, 100, 9, True),
+                                                     ("pallas", 11, 2000, 40, True), ("pallas", 12, 1 << 12, 33, False),
+                                                     ("vesta", 9, 300, 5, True), ("pallas", 10, 1 << 10, 0, True)])
+def test_rank_one_eq_rounds_vs_oracle(curve, ell, n_t, nq, fused, gpu_lib, monkeypatch):
+    """gen_eq_table's table kept as FH (x) FL + point masses while the rounds fold FH bits (never written out): forced on at
+    sizes the oracle handles (by default it serves tables of 2^22 entries and more), every round's coefficients, the folded
+    tables, a look at EQ between rounds, repeated and colliding lookup indices, masses in both halves."""
+    from reef_amd.sumcheck import SumCheck
+    from oracle.pasta_oracle import CURVES
+    monkeypatch.setenv("REEF_SC_RANK1_MIN_POW", "1")
+    q = CURVES[curve].order
+    rng = SplitMix64(ell * 77 + nq)
+    table = [uniform_scalar(rng, q) for _ in range(n_t)]
+    n = 1 << ell
+    qs = [rng.next() % n for _ in range(nq)]
+    if nq >= 3:
+        qs[1] = qs[0]                                            # the same index twice
+        qs[2] = qs[0] ^ (n >> 1)                                 # its partner in round 1: the masses meet after the first fold
+    if nq >= 5:
+        qs[3], qs[4] = 0, n - 1
+    rs = [uniform_scalar(rng, q) for _ in range(nq + 1)]
+    last_q = [uniform_scalar(rng, q) for _ in range(ell)]
+    t = table + [0] * (n - n_t)
+    e = gen_eq_table(rs, qs, last_q, q)
+    with SumCheck(curve, ell) as sc:
+        sc.set_table(0, table)
+        for step in range(2):                                    # two folding steps on the same context (reset + a fresh EQ)
+            tt, ee = list(t), list(e)
+            sc.reset_table()
+            sc.gen_eq_table(rs, qs, last_q)
+            if step == 1:
+                assert sc.read(1, n) == ee                       # written out for the reader; the rounds go on rank-one
+            g = sc.round_coeffs(1)
+            for i in range(1, ell + 1):
+                assert g == linear_mle_coeffs(tt, ee, ell, i, q), (step, i)
+                r = uniform_scalar(rng, q) if i != 2 else (0 if step == 0 else 1)     # the trivial challenges once
+                linear_mle_fold(tt, ee, ell, i, r, q)
+                live = 1 << (ell - i)
+                if fused and i < ell:
+                    g = sc.fold_and_next_coeffs(i, r)
+                else:
+                    sc.fold(i, r)
+                    if i < ell:
+                        g = sc.round_coeffs(i + 1)
+                if i in (1, ell // 2, ell):
+                    assert sc.read(0, live) == tt[:live], (step, i)
+                    assert sc.read(1, live) == ee[:live], (step, i)
+            assert sc.read(0, 1) == [tt[0]] and sc.read(1, 1) == [ee[0]]
+
+
+def test_rank_one_matches_dense_at_default_size(gpu_lib, monkeypatch):
+    """2^22 entries (the smallest table the rank-one rounds serve by default): the transcript of a whole folding step equals the
+    dense form's (REEF_SC_RANK1=0), the sum-check identity holds round after round, and the final claim is T~(r) * EQ~(r)."""
+    from reef_amd.sumcheck import SumCheck
+    from reef_amd import msm
+    ell = 22
+    n = 1 << ell
+    d_doc = msm.gen_scalars("pallas", 0xD0C, n, kind=2, small_bound=131, mont=False, device=True)
+    rng = SplitMix64(2222)
+    nq = 33
+    rs = [uniform_scalar(rng, Q) for _ in range(nq + 1)]
+    qs = [rng.next() % n for _ in range(nq)]
+    last_q = [uniform_scalar(rng, Q) for _ in range(ell)]
+    challenges = [uniform_scalar(rng, Q) for _ in range(ell)]
+    transcripts = []
+    with SumCheck("pallas", ell) as sc:
+        sc.set_table_device(0, d_doc.ptr, n)
+        for mode in ("1", "0"):
+            monkeypatch.setenv("REEF_SC_RANK1", mode)
+            sc.reset_table()
+            sc.gen_eq_table(rs, qs, last_q)
+            tr = []
+            xsq, x, con = sc.round_coeffs(1)
+            claim = (2 * con + x + xsq) % Q
+            for i in range(1, ell + 1):
+                tr.append((xsq, x, con))
+                r = challenges[i - 1]
+                claim = (xsq * r * r + x * r + con) % Q
+                if i < ell:
+                    xsq, x, con = sc.fold_and_next_coeffs(i, r)
+                    assert claim == (2 * con + x + xsq) % Q, (mode, i + 1)
+                else:
+                    sc.fold(i, r)
+            t0, e0 = sc.read(0, 1)[0], sc.read(1, 1)[0]
+            assert claim == t0 * e0 % Q
+            transcripts.append((tr, t0, e0))
+    assert transcripts[0] == transcripts[1]

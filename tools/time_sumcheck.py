@@ -47,6 +47,38 @@ for ell in [int(x) for x in sys.argv[1:]] or [21, 24, 26]:
                 t_first = time.perf_counter() - t0
         total_fused = time.perf_counter() - t_f
         print(f"ell={ell}: fused fold+coeffs: all rounds {total_fused*1e3:.2f} ms; round 1 {t_first*1e3:.3f} ms = {96*n/t_first/1e9:.0f} GB/s", flush=True)
+        # one folding step as wit_nlookup_gadget runs it (r1cs.rs:2320-2376): T from its pristine copy, gen_eq_table, ell rounds.
+        # REEF_SC_RANK1=0 is the dense form of rounds 1-2 (EQ written out and streamed beside T)
+        nq = 33
+        rs = [(0x1234567 * (k + 3)) % Q for k in range(nq + 1)]
+        qs = [(0x9E3779B1 * (k + 1)) % n for k in range(nq)]
+        lq = [(0x7654321 * (k + 5)) % Q for k in range(ell)]
+        for mode in ("1", "0"):
+            os.environ["REEF_SC_RANK1"] = mode
+            best = None
+            for rep in range(3):
+                sc.reset_table(); sc.sync()
+                t0 = time.perf_counter()
+                sc.gen_eq_table(rs, qs, lq)
+                t_eq = time.perf_counter() - t0
+                xsq, x, con = sc.round_coeffs(1)
+                t_r1 = time.perf_counter() - t0 - t_eq
+                t_f1 = None
+                for i in range(1, ell + 1):
+                    rch = (xsq * 7 + 3) % Q
+                    t1 = time.perf_counter()
+                    if i < ell:
+                        xsq, x, con = sc.fold_and_next_coeffs(i, rch)
+                    else:
+                        sc.fold(i, rch); sc.sync()
+                    if i == 1:
+                        t_f1 = time.perf_counter() - t1
+                tot = time.perf_counter() - t0
+                if best is None or tot < best[0]:
+                    best = (tot, t_eq, t_r1, t_f1, sc.read(0, 1)[0])
+            print(f"ell={ell}: one folding step, EQ {'rank-one (never written out)' if mode == '1' else 'dense'}: {best[0]*1e3:.2f} ms "
+                  f"(gen_eq_table {best[1]*1e3:.3f}, round-1 sums {best[2]*1e3:.3f}, first fused round {best[3]*1e3:.3f}); T~(r) = {best[4] & 0xffffffff:08x}", flush=True)
+        os.environ.pop("REEF_SC_RANK1", None)
         gb_c, gb_f = 64 * n / 1e9, 96 * n / 1e9    # round 1: coeffs read 2 tables, fold reads 2 and writes half
         print(f"ell={ell}: all {ell} rounds {total*1e3:.2f} ms (coeffs {t_coeff*1e3:.2f}, folds {t_fold*1e3:.2f}); "
               f"round 1: coeffs {first[0]*1e3:.3f} ms = {gb_c/first[0]:.0f} GB/s, fold {first[1]*1e3:.3f} ms = {gb_f/first[1]:.0f} GB/s "
