@@ -22,6 +22,8 @@ ALGO = {
     "k_sc_coeffs<1>": ("round 1 at ell = 26: reads both tables once", 2 * N26 * 32),
     "k_sc_fold<1>": ("fold with pow = 2^25: reads both tables, writes half of each", 2 * N26 * 32 + 2 * N25 * 32),
     "k_sc_fold_coeffs<1>": ("fused fold + next coefficients with pow = 2^25: reads both tables, writes half of each", 2 * N26 * 32 + 2 * N25 * 32),
+    "k_sc_r1_coeffs<1>": ("round 1 at ell = 26 with EQ rank-one: reads T once (EQ is two factor tables of 2^13 entries)", N26 * 32),
+    "k_sc_r1_fold_coeffs<1>": ("fused fold + next coefficients with pow = 2^25, EQ rank-one: reads T, writes half of it", N26 * 32 + N25 * 32),
     "k_sc_eq_table<1>": ("eq table of 2^26 entries: written once (its two factor tables are cache-resident)", N26 * 32),
     "k_mle_bound<1, 32>": ("bound rows of a 2^25 x 32 B table: read once", N25 * 32),
 }
