@@ -257,3 +257,134 @@ def test_rank_one_matches_dense_at_default_size(gpu_lib, monkeypatch):
             assert claim == t0 * e0 % Q
             transcripts.append((tr, t0, e0))
     assert transcripts[0] == transcripts[1]
+
+
+def _structured_table(kind, ell, rng, q):
+    """Tables with the row structure of Reef's own (matrix view of 2^(ell//2) columns): a transition-table stub and one repeated
+    fill value in the first half, symbols and zeros in the second (r1cs.rs:481-484, :2105-2112) -- and harder mixes."""
+    n = 1 << ell
+    cols = 1 << (ell // 2)
+    rows = n // cols
+    fill = uniform_scalar(rng, q)
+    t = []
+    for r in range(rows):
+        if kind == "hybrid":
+            if r == 0:
+                row = [uniform_scalar(rng, q) for _ in range(cols)]                    # transitions: wide
+            elif r < rows // 2:
+                row = [fill] * cols                                                   # calc_fill up to the half
+            elif r < rows - max(1, rows // 8):
+                row = [rng.next() % 7 for _ in range(cols)]                           # symbols
+            else:
+                row = [0] * cols                                                      # padding
+        elif kind == "document":
+            row = [rng.next() % 131 for _ in range(cols)]
+        else:                                                                         # "mixed": every class on both sides, edges of "small"
+            pick = (r * 7 + 3) % 5
+            if pick == 0:
+                row = [uniform_scalar(rng, q) for _ in range(cols)]
+            elif pick == 1:
+                row = [(1 << 30) - 1 - (rng.next() % 3) for _ in range(cols)]         # the largest small entries
+            elif pick == 2:
+                row = [q - 1] * cols                                                  # constant, as large as it gets
+            elif pick == 3:
+                row = [5] * cols                                                      # constant and small: a K row
+            else:
+                row = [rng.next() % 4 for _ in range(cols)]
+                if r % 2:
+                    row[-1] = 1 << 30                                                 # one entry too large: the row is wide
+        t += row
+    return t
+
+
+@pytest.mark.parametrize("kind,ell,nq,fused", [("hybrid", 10, 7, True), ("hybrid", 11, 40, True), ("document", 8, 3, True), ("mixed", 10, 9, True),
+                                               ("mixed", 12, 33, False), ("hybrid", 6, 2, True), ("mixed", 7, 5, True)])
+def test_structured_pristine_table_vs_oracle(kind, ell, nq, fused, gpu_lib, monkeypatch):
+    """The first round of a folding step on a table with constant rows and rows of small entries (closed forms, 4-byte reads),
+    forced on at sizes the oracle handles: coefficients of every round, the folded table after the first fold, two steps."""
+    from reef_amd.sumcheck import SumCheck
+    monkeypatch.setenv("REEF_SC_RANK1_MIN_POW", "1")
+    q = Q
+    rng = SplitMix64(ell * 131 + nq)
+    t = _structured_table(kind, ell, rng, q)
+    n = 1 << ell
+    n_t = n if kind != "document" else n - 37                   # the last row of a document is cut short: zero padding
+    t = t[:n_t] + [0] * (n - n_t)
+    qs = [rng.next() % n for _ in range(nq)]
+    qs[0] = 0
+    qs[-1] = n - 1
+    rs = [uniform_scalar(rng, q) for _ in range(nq + 1)]
+    last_q = [uniform_scalar(rng, q) for _ in range(ell)]
+    e = gen_eq_table(rs, qs, last_q, q)
+    with SumCheck("pallas", ell) as sc:
+        sc.set_table(0, t[:n_t])
+        for step in range(2):
+            tt, ee = list(t), list(e)
+            sc.reset_table()
+            sc.gen_eq_table(rs, qs, last_q)
+            g = sc.round_coeffs(1)
+            for i in range(1, ell + 1):
+                assert g == linear_mle_coeffs(tt, ee, ell, i, q), (kind, step, i)
+                r = uniform_scalar(rng, q) if not (step == 1 and i == 1) else q - 1
+                linear_mle_fold(tt, ee, ell, i, r, q)
+                live = 1 << (ell - i)
+                if fused and i < ell:
+                    g = sc.fold_and_next_coeffs(i, r)
+                else:
+                    sc.fold(i, r)
+                    if i < ell:
+                        g = sc.round_coeffs(i + 1)
+                if i <= 2:
+                    assert sc.read(0, live) == tt[:live], (kind, step, i)
+            assert sc.read(0, 1) == [tt[0]] and sc.read(1, 1) == [ee[0]]
+    # the same transcript without the structure
+    monkeypatch.setenv("REEF_SC_STRUCT", "0")
+    with SumCheck("pallas", ell) as sc:
+        sc.set_table(0, t[:n_t])
+        sc.gen_eq_table(rs, qs, last_q)
+        assert sc.round_coeffs(1) == linear_mle_coeffs(t, e, ell, 1, q)
+
+
+def test_structured_table_at_cfg4_shape(gpu_lib, monkeypatch):
+    """2^24 entries shaped like the hybrid table of BASELINE's cfg4 (first half: a few transition rows, then one value; second
+    half: DNA symbols, then zeros): the transcript of a folding step equals the one taken without the structure and the dense one."""
+    from reef_amd.sumcheck import SumCheck
+    ell = 24
+    n = 1 << ell
+    cols = 1 << (ell // 2)
+    rng = SplitMix64(2424)
+    fill = uniform_scalar(rng, Q)
+    arr = np.zeros((n, 4), dtype=np.uint64)
+    head = 3 * cols + 17                                        # transitions spill into a fourth row
+    for i in range(head):
+        v = uniform_scalar(rng, Q)
+        arr[i] = [(v >> (64 * k)) & 0xFFFFFFFFFFFFFFFF for k in range(4)]
+    arr[head:n // 2] = [(fill >> (64 * k)) & 0xFFFFFFFFFFFFFFFF for k in range(4)]
+    doc_len = n // 2 - 12345
+    arr[n // 2:n // 2 + doc_len, 0] = np.random.default_rng(5).integers(0, 7, size=doc_len, dtype=np.uint64)
+    nq = 33
+    rs = [uniform_scalar(rng, Q) for _ in range(nq + 1)]
+    qs = [rng.next() % n for _ in range(nq)]
+    last_q = [uniform_scalar(rng, Q) for _ in range(ell)]
+    challenges = [uniform_scalar(rng, Q) for _ in range(ell)]
+    from reef_amd import msm
+    d_tab = msm.DeviceBuffer.from_host(arr)
+    transcripts = []
+    for env in ({}, {"REEF_SC_STRUCT": "0"}, {"REEF_SC_RANK1": "0"}):
+        for k in ("REEF_SC_STRUCT", "REEF_SC_RANK1"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        with SumCheck("pallas", ell) as sc:
+            sc.set_table_device(0, d_tab.ptr, n)
+            sc.gen_eq_table(rs, qs, last_q)
+            tr = []
+            g = sc.round_coeffs(1)
+            for i in range(1, ell + 1):
+                tr.append(g)
+                if i < ell:
+                    g = sc.fold_and_next_coeffs(i, challenges[i - 1])
+                else:
+                    sc.fold(i, challenges[i - 1])
+            transcripts.append((tr, sc.read(0, 1)[0], sc.read(1, 1)[0]))
+    assert transcripts[0] == transcripts[1] == transcripts[2]

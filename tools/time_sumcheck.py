@@ -47,6 +47,46 @@ for ell in [int(x) for x in sys.argv[1:]] or [21, 24, 26]:
                 t_first = time.perf_counter() - t0
         total_fused = time.perf_counter() - t_f
         print(f"ell={ell}: fused fold+coeffs: all rounds {total_fused*1e3:.2f} ms; round 1 {t_first*1e3:.3f} ms = {96*n/t_first/1e9:.0f} GB/s", flush=True)
+        # the table shaped like Reef's hybrid table (r1cs.rs:481-484, :2105-2112): transitions and one repeated value in the first
+        # half, document symbols and zeros in the second; REEF_SC_STRUCT=0 reads it as dense field elements all the same
+        import numpy as np
+        cols = 1 << (ell // 2)
+        hyb = np.zeros((n, 4), dtype=np.uint64)
+        rngn = np.random.default_rng(7)
+        hyb[:3 * cols + 17] = rngn.integers(0, 1 << 62, size=(3 * cols + 17, 4), dtype=np.uint64)
+        hyb[3 * cols + 17:n // 2] = np.array([0x123456789abcdef1, 0x0fedcba987654321, 0x1111111122222222, 0x0333333344444444], dtype=np.uint64)
+        hyb[n // 2:n - n // 16, 0] = rngn.integers(0, 7, size=n // 2 - n // 16, dtype=np.uint64)
+        d_hyb = msm.DeviceBuffer.from_host(hyb)
+        del hyb
+        for mode in ("1", "0"):
+            os.environ["REEF_SC_STRUCT"] = mode
+            sc.set_table_device(0, d_hyb.ptr, n)
+            best = None
+            for rep in range(3):
+                sc.reset_table(); sc.sync()
+                t0 = time.perf_counter()
+                sc.gen_eq_table([(0x1234567 * (k + 3)) % Q for k in range(34)], [(0x9E3779B1 * (k + 1)) % n for k in range(33)], [(0x7654321 * (k + 5)) % Q for k in range(ell)])
+                t_eq = time.perf_counter() - t0
+                xsq, x, con = sc.round_coeffs(1)
+                t_r1 = time.perf_counter() - t0 - t_eq
+                t_f1 = None
+                for i in range(1, ell + 1):
+                    rch = (xsq * 7 + 3) % Q
+                    t1 = time.perf_counter()
+                    if i < ell:
+                        xsq, x, con = sc.fold_and_next_coeffs(i, rch)
+                    else:
+                        sc.fold(i, rch); sc.sync()
+                    if i == 1:
+                        t_f1 = time.perf_counter() - t1
+                tot = time.perf_counter() - t0
+                if best is None or tot < best[0]:
+                    best = (tot, t_eq, t_r1, t_f1, sc.read(0, 1)[0])
+            print(f"ell={ell}: one folding step on a hybrid-shaped table, {'row structure used' if mode == '1' else 'read as dense field elements'}: {best[0]*1e3:.2f} ms "
+                  f"(round-1 sums {best[2]*1e3:.3f}, first fused round {best[3]*1e3:.3f}); T~(r) = {best[4] & 0xffffffff:08x}", flush=True)
+        os.environ.pop("REEF_SC_STRUCT", None)
+        d_hyb.free()
+        sc.set_table_device(0, doc.ptr, n)
         # one folding step as wit_nlookup_gadget runs it (r1cs.rs:2320-2376): T from its pristine copy, gen_eq_table, ell rounds.
         # REEF_SC_RANK1=0 is the dense form of rounds 1-2 (EQ written out and streamed beside T)
         nq = 33
