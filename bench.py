@@ -168,8 +168,8 @@ def hbm_bound_leg(ell=26):
     from reef_amd import msm
     from reef_amd.sumcheck import SumCheck
     n = 1 << ell
-    doc = msm.gen_scalars("pallas", 0xD0C, n, kind=2, small_bound=1 << 20, mont=False, device=True)
-    eqv = msm.gen_scalars("pallas", 0xE9, n, kind=0, mont=False, device=True)
+    doc = msm.gen_scalars("pallas", 0xD0C, n, kind=0, mont=False, device=True)   # full-width entries: no row of the table is constant or small,
+    eqv = msm.gen_scalars("pallas", 0xE9, n, kind=0, mont=False, device=True)   # so round one streams 32-byte entries like every later round
     nq = 33
     rs = [(0x1234567 * (k + 3)) % Q for k in range(nq + 1)]
     qs = [(0x9E3779B1 * (k + 1)) % n for k in range(nq)]

@@ -486,7 +486,20 @@ static std::string replay_body(const Shape &shape, bool nofold, bool tables, con
         const sc_ptr sc_owner(sc);
         dev_ptr<reef_fe> tab_owner = device_alloc<reef_fe>(len);
         reef_fe *d_tab = tab_owner.get();
-        CK(reef_gen_scalars(REEF_PALLAS, 0x7AB1E, 2, 1u << 20, len, false, d_tab, REEF_DEVICE));   // packed lookup values, canonical
+        // the table as Reef builds it (canonical integers): --hybrid puts the transition table and then ONE value (`calc_fill`)
+        // in the public half and the document in the private half (r1cs.rs:481-484, :2105-2112); otherwise it is the document
+        const uint64_t sym_bound = 1ull << sh->symbol_bits;
+        if (sh->table_log == sh->doc_log + 1) {
+            const size_t half = len / 2, trans = std::min<size_t>(256, half / 2);
+            CK(reef_gen_scalars(REEF_PALLAS, 0x7AB1E, 0, 0, trans, false, d_tab, REEF_DEVICE));
+            const reef_fe fill = {{0x123456789abcdef1ULL, 0x0fedcba987654321ULL, 0x1111111122222222ULL, 0x0333333344444444ULL}};
+            CK(reef_memcpy(d_tab + trans, &fill, sizeof fill, REEF_DEVICE, REEF_HOST));
+            for (size_t have = 1; trans + have < half; have *= 2)
+                CK(reef_memcpy(d_tab + trans + have, d_tab + trans, std::min(have, half - trans - have) * sizeof(reef_fe), REEF_DEVICE, REEF_DEVICE));
+            CK(reef_gen_scalars(REEF_PALLAS, 0xD0C, 2, sym_bound, half, false, d_tab + half, REEF_DEVICE));
+        } else {
+            CK(reef_gen_scalars(REEF_PALLAS, 0xD0C, 2, sym_bound, len, false, d_tab, REEF_DEVICE));
+        }
         CK(reef_sc_set_table(sc, 0, d_tab, len, REEF_DEVICE));
         tab_owner.reset();
         run_sumcheck_step(sc, sh->table_log, sh->lookups);            // warm-up
