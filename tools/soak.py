@@ -112,9 +112,25 @@ while time.time() < t_end:
             zi = [int.from_bytes(rng.bytes(32), "little") % mod for _ in range(n)]
             z = zi
         assert mle.bound_rows("pallas" if cid == 0 else "vesta", z, point, left) == mle_oracle.bound_rows(zi, point, left, mod), ("mle", cid, m, left, n)
-    elif shape == 5:    # a whole sum-check (pallas scalar field)
-        ell = int(rng.integers(1, 11))
-        table = [int(rng.integers(0, 1 << 30)) for _ in range(int(rng.integers(1 << (ell - 1), (1 << ell) + 1)))]
+    elif shape == 5:    # a whole sum-check (pallas scalar field); half the time with the rank-one EQ rounds and the row structure of
+        ell = int(rng.integers(1, 11))                          # the pristine table forced on at this size
+        if rng.random() < 0.5:
+            os.environ["REEF_SC_RANK1_MIN_POW"] = "1"
+        else:
+            os.environ.pop("REEF_SC_RANK1_MIN_POW", None)
+        cols = 1 << (ell // 2)
+        table = []
+        for _row in range((1 << ell) // cols):
+            pick = int(rng.integers(0, 4))
+            if pick == 0:
+                table += [int.from_bytes(rng.bytes(32), "little") % S.Q for _ in range(cols)]
+            elif pick == 1:
+                table += [int(rng.integers(0, 1 << 30)) for _ in range(cols)]
+            elif pick == 2:
+                table += [int.from_bytes(rng.bytes(32), "little") % S.Q] * cols
+            else:
+                table += [int(rng.integers(0, 7)) for _ in range(cols)]
+        table = table[:int(rng.integers(1 << (ell - 1), (1 << ell) + 1))]
         nq = int(rng.integers(1, 6))
         qs = [int(rng.integers(0, 1 << ell)) for _ in range(nq)]
         rs = [int.from_bytes(rng.bytes(32), "little") % S.Q for _ in range(nq + 1)]
@@ -124,12 +140,20 @@ while time.time() < t_end:
         with SumCheck("pallas", ell) as sc:
             sc.set_table(0, table)
             sc.gen_eq_table(rs, qs, last_q)
+            fused = rng.random() < 0.5
+            g = sc.round_coeffs(1)
             for i in range(1, ell + 1):
-                assert sc.round_coeffs(i) == S.linear_mle_coeffs(t, e, ell, i), ("sc", ell, i)
+                assert g == S.linear_mle_coeffs(t, e, ell, i), ("sc", ell, i, fused, os.environ.get("REEF_SC_RANK1_MIN_POW"))
                 r = int.from_bytes(rng.bytes(32), "little") % S.Q
-                sc.fold(i, r)
                 S.linear_mle_fold(t, e, ell, i, r)
-            assert sc.read(0, 1)[0] == t[0]
+                if fused and i < ell:
+                    g = sc.fold_and_next_coeffs(i, r)
+                else:
+                    sc.fold(i, r)
+                    if i < ell:
+                        g = sc.round_coeffs(i + 1)
+            assert sc.read(0, 1)[0] == t[0] and sc.read(1, 1)[0] == e[0]
+        os.environ.pop("REEF_SC_RANK1_MIN_POW", None)
     else:               # rows (field elements and symbols)
         big = 2 if os.environ.get("SOAK_BIG") else 0
         rows, row_len = int(2 ** rng.uniform(0, 11 + big)), int(2 ** rng.uniform(0, 12 + big / 2))
