@@ -23,7 +23,11 @@ ALGO = {
     "k_sc_fold<1>": ("fold with pow = 2^25: reads both tables, writes half of each", 2 * N26 * 32 + 2 * N25 * 32),
     "k_sc_fold_coeffs<1>": ("fused fold + next coefficients with pow = 2^25: reads both tables, writes half of each", 2 * N26 * 32 + 2 * N25 * 32),
     "k_sc_r1_coeffs<1>": ("round 1 at ell = 26 with EQ rank-one: reads T once (EQ is two factor tables of 2^13 entries)", N26 * 32),
-    "k_sc_r1_fold_coeffs<1>": ("fused fold + next coefficients with pow = 2^25, EQ rank-one: reads T, writes half of it", N26 * 32 + N25 * 32),
+    "k_sc_r1_fold_coeffs<1, false>": ("fused fold + next coefficients with pow = 2^25, EQ rank-one: reads T, writes half of it", N26 * 32 + N25 * 32),
+    # the hybrid-shaped table of tools/time_sumcheck.py at ell = 26: 8192 rows of 8192 entries; second half = 3584 rows of symbols + 512 zero rows
+    "k_sc_r1s_rows<1, false>": ("round-1 sums over the 3584 symbol rows of the hybrid-shaped table: 4-byte entries read once", 3584 * 8192 * 4),
+    "k_sc_r1_fold_coeffs_cs<1, false>": ("first fold of the hybrid-shaped table (2047 of 2048 row quadruples constant-or-small): 4-byte reads of the "
+                                         "symbol rows, the folded table written as field elements", 3584 * 8192 * 4 + 2 * 2047 * 8192 * 32),
     "k_sc_eq_table<1>": ("eq table of 2^26 entries: written once (its two factor tables are cache-resident)", N26 * 32),
     "k_mle_bound<1, 32>": ("bound rows of a 2^25 x 32 B table: read once", N25 * 32),
 }
