@@ -202,6 +202,12 @@ reef_status reef_gen_scalars(int curve, uint64_t seed, int kind, uint64_t small_
  *                                                        Poseidon challenge the host derived (:478-489)
  *   prover_mle_partial_eval(table, sc_rs)  :551-634   -> after the last round the folded table holds
  *                                                        the value in entry 0: reef_sc_read(ctx, 0, 1, ..)
+ * The results are the reference's whatever happens inside; what happens inside when the calls come in the reference's
+ * order (reset, gen_eq_table, rounds with halving pow): the EQ table of gen_eq_table is a rank-one table (two factor
+ * tables) plus the lookup points and is kept as that while the rounds fold its high index bits -- nothing of 2^ell
+ * entries is written for it, a round streams T only; and the first round of a step reads T through the row structure
+ * reef_sc_set_table found (constant rows, rows of small entries such as document symbols).  A caller-given EQ
+ * (which = 1), reef_sc_read(ctx, 1, ..) between rounds, or a round out of order: dense tables from there on.
  * ------------------------------------------------------------------------------------------- */
 typedef struct reef_sc_ctx reef_sc_ctx;
 /* Two resident tables (T = lookup table or document, EQ) of table_len = 2^ell entries each. */

@@ -31,6 +31,7 @@ PY
 )
 python $root/tools/time_rows.py 1024 2048 131 > $out/${R}_rows_timing.txt 2>&1; python $root/tools/time_rows.py 4096 8192 7 >> $out/${R}_rows_timing.txt 2>&1
 python $root/tools/time_sumcheck.py 21 26 > $out/${R}_sumcheck_timing.txt 2>&1
+$root/reef_amd/_lib/sync_probe > $out/${R}_sync_probe.txt 2>&1
 python $root/tools/time_mle.py > $out/${R}_mle_timing.txt 2>&1
 (python $root/tools/time_merkle.py 16 20 24 26 27; echo "# REEF_POSEIDON_DENSE=1 (partial rounds in the defining dense form), same box:"; REEF_POSEIDON_DENSE=1 python $root/tools/time_merkle.py 20 24 26 | grep symbols) > $out/${R}_merkle_timing.txt 2>&1
 python $root/tools/time_keygen.py $out/${R}_keygen_timing.json > /dev/null 2>&1
