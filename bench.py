@@ -222,6 +222,7 @@ def replay_leg():
                 "w1": g["w1"], "c1": g["c1"], "w2": g["w2"], "c2": g["c2"], "steps": g["steps"],
                 "fold_ms_per_step": g["ms_per_step"], "fold_ms_per_step_batched_pairs": g["ms_per_step_batched_pairs"],
                 "ipa_ms": g["ipa_pallas_ms"] + g["ipa_vesta_ms"], "consistency_ipa_ms": g["consistency_ipa_ms"],
+                "three_arguments_concurrently_ms": g.get("three_arguments_concurrently_ms"),
                 "total_prove_msm_ms": g["total_prove_msm_ms"], "total_prove_gpu_ms": g["total_prove_gpu_ms"], "setup_ms": g["setup_ms"],
                 "commitments_checked_against_dlog": g["commitments_checked_against_dlog"],
                 "scalars": "host memory in, commitments back to the host (PCIe-inclusive)", "ipa": g["ipa"]})

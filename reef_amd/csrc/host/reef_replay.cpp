@@ -35,6 +35,7 @@
 #include <memory>
 #include <stdexcept>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "reef_msm.h"
@@ -439,9 +440,10 @@ static std::string replay_body(const Shape &shape, bool nofold, bool tables, con
     const double ipa2_ms = nofold ? run_ipa_nofold(cv[1], cv[1].n, sT2, &r2) : run_ipa(cv[1], cv[1].n, sT2, &r2);
     const double final_ms = ms_since(t_final);
 
-    double cons_ms = 0;
+    double cons_ms = 0, concurrent_ms = 0;
+    Curve hy;
+    ctx_ptr hy_owner;
     if (sh->hyrax_row >= 2) {
-        Curve hy;
         hy.id = REEF_PALLAS; hy.n = sh->hyrax_row; hy.d_gens = cv[0].d_gens;  // prefix of the same key shape
         for (int k = 0; k < 2; ++k) hy.ipa[k] = cv[0].ipa[k];
         if (nofold) {   // the Hyrax row generators are a resident key of their own (commitment.rs:176-186)
@@ -450,13 +452,30 @@ static std::string replay_body(const Shape &shape, bool nofold, bool tables, con
             o.byte_tables = tables ? 1 : 2;
             o.device = -1;
             CK(reef_msm_ctx_create(&hy.key, hy.id, hy.d_gens, hy.n, REEF_DEVICE, &o));
-            const ctx_ptr hy_owner(hy.key);
+            hy_owner.reset(hy.key);
             reef_jacobian warm_l, warm_r;
             CK(reef_ipa_cross_terms(hy.key, sT1, hy.n, REEF_DEVICE, true, nullptr, nullptr, 0, &warm_l, &warm_r));
             cons_ms = run_ipa_nofold(hy, hy.n, sT1, &r3);
         } else {
             cons_ms = run_ipa(hy, hy.n, sT1, &r3);
         }
+    }
+
+    // The two Spartan arguments (primary and secondary curve) and the consistency argument do not depend on one another: issued
+    // from three caller threads at once -- what rayon::join around them does -- their latency-bound rounds share the GPU.
+    if (nofold) {
+        std::exception_ptr err[2];
+        auto guarded = [&](int k, Curve &c, const reef_fe *sc) {
+            try { run_ipa_nofold(c, c.n, sc, nullptr); } catch (...) { err[k] = std::current_exception(); }
+        };
+        auto tc = clk::now();
+        std::thread a(guarded, 0, std::ref(cv[0]), (const reef_fe *)sT1), b(guarded, 1, std::ref(cv[1]), (const reef_fe *)sT2);
+        if (hy.key) run_ipa_nofold(hy, hy.n, sT1, nullptr);
+        a.join();
+        b.join();
+        concurrent_ms = ms_since(tc);
+        for (auto &e : err)
+            if (e) std::rethrow_exception(e);
     }
 
     // ---- commitment of the document, the per-step sum-check and the document polynomial at proof end
@@ -545,12 +564,12 @@ static std::string replay_body(const Shape &shape, bool nofold, bool tables, con
            "\"scalars\": \"per-step vectors in host memory, commitments returned to the host (PCIe inclusive)\", \"commitments_checked_against_dlog\": %d, "
            "\"key_pallas\": %zu, \"key_vesta\": %zu, \"steps\": %d, \"setup_ms\": %.3f, \"fold_steps_ms\": %.3f, \"ms_per_step\": %.3f, "
            "\"ms_per_step_batched_pairs\": %.3f, \"pairs_per_step\": %zu, \"final_snark_ms\": %.3f, \"ipa_pallas_ms\": %.3f, \"ipa_pallas_rounds\": %d, \"ipa_vesta_ms\": %.3f, "
-           "\"ipa_vesta_rounds\": %d, \"consistency_ipa_ms\": %.3f, \"consistency_rounds\": %d, \"total_prove_msm_ms\": %.3f, "
+           "\"ipa_vesta_rounds\": %d, \"consistency_ipa_ms\": %.3f, \"consistency_rounds\": %d, \"three_arguments_concurrently_ms\": %.3f, \"total_prove_msm_ms\": %.3f, "
            "\"commit_hyrax_ms\": %.3f, \"commit_hyrax_first_call_ms\": %.3f, \"sumcheck_table_log\": %d, \"sumcheck_ms_per_step\": %.3f, "
            "\"doc_poly_bind_rows_ms\": %.3f, \"total_prove_gpu_ms\": %.3f, \"derive_both_keys_ms\": %.3f, \"commit_merkle_log\": %d, \"commit_merkle_ms\": %.3f, "
            "\"standins\": \"key derivation and Poseidon run on stand-in parameter sets (replay_standins.h), timing only\", \"byte_tables\": %s}",
            sh->name.c_str(), nofold ? "cross terms over the original key (no generator fold)" : "generator fold per round", shapes_path.c_str(), sh->w1, sh->c1, sh->w2, sh->c2, g_checked, cv[0].n, cv[1].n, sh->steps, setup_ms, steps_ms, steps_ms / sh->steps, steps_batched_ms / sh->steps, pairs_step, final_ms, ipa1_ms, r1, ipa2_ms, r2,
-           cons_ms, r3, steps_ms + final_ms + cons_ms, commit_ms, commit_first_ms, sh->table_log, sc_step_ms, mle_ms,
+           cons_ms, r3, concurrent_ms, steps_ms + final_ms + cons_ms, commit_ms, commit_first_ms, sh->table_log, sc_step_ms, mle_ms,
            steps_ms + final_ms + cons_ms + sh->steps * sc_step_ms + mle_ms, derive_ms, sh->merkle_log, merkle_ms,
            tables ? "\"built with the keys (inside setup_ms): MSMs of 1025..65536 points are sums of table entries\"" : "\"none (bucket pipeline)\"");
     return std::string(line.data());        // the owners above release every context and device buffer, here or on an exception
