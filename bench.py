@@ -252,6 +252,10 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world > 1 and world != a.gpus:
         raise SystemExit(f"bench.py: --gpus {a.gpus} but WORLD_SIZE={world}: launch one rank per GPU (torch.distributed.run --nproc-per-node {a.gpus})")
+    # more hardware queues than the runtime's default four, before anything initialises HIP: caller threads' streams that share a
+    # queue run one after the other (reef_amd/csrc/api.cpp; the library asks for the same when it is loaded first)
+    if os.environ.get("REEF_MSM_HW_QUEUES", "") != "0":
+        os.environ.setdefault("GPU_MAX_HW_QUEUES", os.environ.get("REEF_MSM_HW_QUEUES") or "8")
     import numpy as np
     import torch
     import torch.distributed as dist

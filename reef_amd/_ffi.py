@@ -12,6 +12,10 @@ from ctypes import POINTER, c_bool, c_char_p, c_double, c_float, c_int, c_int32,
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
+# the library asks the HIP runtime for eight hardware queues when it is loaded (api.cpp); a process that initialises HIP before
+# loading it (torch) gets the same if this module is imported first
+if os.environ.get("REEF_MSM_HW_QUEUES", "") != "0":
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", os.environ.get("REEF_MSM_HW_QUEUES") or "8")
 LIB_PATH = os.environ.get("REEF_MSM_LIB") or os.path.join(_HERE, "_lib", "libreef_msm.so")   # REEF_MSM_LIB: another build of the same library (experiments)
 HEADER = os.path.join(os.path.dirname(_HERE), "include", "reef_msm.h")
 

@@ -26,6 +26,22 @@ void set_error(const char *fmt, ...) {
     va_end(ap);
 }
 
+// The HIP runtime multiplexes a process's streams onto GPU_MAX_HW_QUEUES hardware queues (4 unless set), and streams that share
+// a queue run one after the other.  One caller thread is a context stream plus its scratch stream: with the three arguments of
+// the final SNARK issued at once that is more than four, and their latency-bound rounds queue up behind each
+// other -- 8.3 ms against 6.4 ms with eight queues for cfg3, 4 threads of IPA rounds 1.95x against 2.55x one thread
+// (tools/time_concurrent_ipa.py).  The variable is read when the runtime initialises, i.e. at the process's first HIP call:
+// set here, when the library is loaded, unless the user has set it (REEF_MSM_HW_QUEUES=<n> asks for n, =0 leaves it alone).
+namespace {
+struct HwQueues {
+    HwQueues() {
+        const char *o = getenv("REEF_MSM_HW_QUEUES");
+        if (o && o[0] == '0' && o[1] == 0) return;
+        setenv("GPU_MAX_HW_QUEUES", (o && *o) ? o : "8", 0);
+    }
+} g_hw_queues;
+}  // namespace
+
 static const CurveVTable *vt(int curve) {
     if (curve == REEF_PALLAS) return pallas_vtable();
     if (curve == REEF_VESTA) return vesta_vtable();
