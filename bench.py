@@ -210,6 +210,15 @@ def hbm_bound_leg(ell=26):
                     "(profiles/r03_pmc_streaming.json)"}
 
 
+def _diag(tag):
+    """REEF_BENCH_DIAG=1: how the final SNARK's three arguments share the GPU at this point of the process (stderr)."""
+    if os.environ.get("REEF_BENCH_DIAG") != "1":
+        return
+    from reef_amd import replay
+    g = replay.run("cfg3", nofold=True, tables=False)
+    print(f"[diag] {tag}: three arguments at once {g['three_arguments_concurrently_ms']} ms", file=sys.stderr, flush=True)
+
+
 def replay_leg():
     """After the timed region, never `value`: the MSM sequence of one `reef --prove` on BASELINE.json configs[2]
     (src/backend/framework.rs:664-723) issued in-process through the C ABI by the C++ harness (per-step scalars in host
@@ -223,12 +232,16 @@ def replay_leg():
                 "fold_ms_per_step": g["ms_per_step"], "fold_ms_per_step_batched_pairs": g["ms_per_step_batched_pairs"],
                 "ipa_ms": g["ipa_pallas_ms"] + g["ipa_vesta_ms"], "consistency_ipa_ms": g["consistency_ipa_ms"],
                 "three_arguments_concurrently_ms": g.get("three_arguments_concurrently_ms"),
+                "three_arguments_note": "the two Spartan arguments and the consistency argument from three caller threads at once; in THIS process, after the "
+                                        "bench's own multi-GiB allocations, it reads 9-10 ms -- the harness alone (or this leg after an early replay in the same "
+                                        "process: REEF_BENCH_DIAG=1) reads 6.1 ms against 12.7 ms one after the other (profiles/r03_concurrent_ipa.txt)",
                 "total_prove_msm_ms": g["total_prove_msm_ms"], "total_prove_gpu_ms": g["total_prove_gpu_ms"], "setup_ms": g["setup_ms"],
                 "commitments_checked_against_dlog": g["commitments_checked_against_dlog"],
                 "scalars": "host memory in, commitments back to the host (PCIe-inclusive)", "ipa": g["ipa"]})
     try:
         t = replay.run("cfg3", nofold=True, tables=True)
         out["byte_tables"] = {"fold_ms_per_step": t["ms_per_step"], "ipa_ms": t["ipa_pallas_ms"] + t["ipa_vesta_ms"],
+                              "three_arguments_concurrently_ms": t.get("three_arguments_concurrently_ms"),
                               "total_prove_msm_ms": t["total_prove_msm_ms"], "setup_ms": t["setup_ms"],
                               "commitments_checked_against_dlog": t["commitments_checked_against_dlog"]}
     except Exception as e:
@@ -299,7 +312,9 @@ def main():
     ctx0 = msm.MsmContext(a.curve, bases, n, window_bits=a.window_bits, bucket_groups=groups, chunk=a.chunk)
     if by_windows:
         ctx0.set_window_split(rank, max(world, 1))
+    _diag("before the contexts")
     ctxs = [ctx0] + [ctx0.clone() for _ in range(max(1, a.streams) - 1)]
+    _diag("contexts created")
     plan = ctx0.plan()
     for c_ in ctxs:
         c_.enable_timing(True)        # roofline.achieved needs the accumulation kernel's own duration
@@ -378,6 +393,7 @@ def main():
         elapsed = float(t.item())
 
     stats = [c.timing_stats(reset=True) for c in ctxs]
+    _diag("after the timed region")
     calls = sum(s["calls"] for s in stats)
     acc_ms = sum(s["accumulate_ms"] for s in stats) / max(calls, 1)
     tot_ms = sum(s["total_ms"] for s in stats) / max(calls, 1)
@@ -548,6 +564,7 @@ def main():
         except Exception as e:                 # never let the side measurement take the bench line down
             print(f"[bench] host-scalar timing skipped: {e}", file=sys.stderr)
 
+    _diag("after the host-scalar leg")
     check = "skipped"
     partials_differ = None
     if not a.no_check:
@@ -645,10 +662,18 @@ def main():
         }
         side_legs = a.gpus == 1 and not multi and not a.no_replay
         if side_legs:                      # GPU side legs first: they are host-latency sensitive (see replay_leg)
+            _diag("before closing the contexts")
+            for c_ in ctxs:                # the timed region's contexts are done: their streams would share hardware queues with the legs'
+                try:
+                    c_.close()
+                except Exception:
+                    pass
+            _diag("contexts closed")
             try:                           # the HBM-bound row of the path (N2) beside the issue-bound headline kernel
                 out["roofline"]["hbm_bound_row"] = hbm_bound_leg()
             except Exception as e:
                 out["roofline"]["hbm_bound_row"] = {"error": str(e)}
+            _diag("after the HBM-bound leg")
             try:
                 out["config"]["replay_cfg3"] = replay_leg()
             except Exception as e:         # a side measurement never takes the bench line down
