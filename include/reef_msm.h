@@ -19,9 +19,19 @@
  *
  * Threading: all entry points are re-entrant.  A reef_msm_ctx serialises the calls made on it
  * (it owns one HIP stream and one workspace); use one ctx (or clone) per concurrent caller.
+ *
+ * ABI changelog (reef_abi_version()):
+ *   4  round 4: reef_runtime_init / reef_abi_version added; the drop-in symbols' key cache is one table per process
+ *      (clones per calling thread) instead of one cache per thread.
+ *   3  round 3: reef_msm_opts.byte_tables = 0 changed meaning from "build the byte tables in the background" to "follow the
+ *      process-wide policy: none unless REEF_MSM_WIDE=1" -- callers that pass zeroed opts no longer get the byte-table path
+ *      for MSM / IPA unless they ask (1 or 3).  A performance difference only; results are identical.
+ *   2  round 2: byte tables, nibble tables, reef_msm_folded, rows N1-N4.
+ *   1  round 1.
  */
 #ifndef REEF_MSM_H
 #define REEF_MSM_H
+#define REEF_ABI_VERSION 4
 
 #include <stdbool.h>
 #include <stddef.h>
@@ -56,15 +66,25 @@ typedef enum {
  * Montgomery form (what the Rust wrapper passes).  abort()s on error.
  * ------------------------------------------------------------------------------------------- */
 /* (A key that keeps coming back is nominated by a non-cryptographic fingerprint of its uploaded bytes,
- * CONFIRMED byte for byte against a retained device copy, and, from its third call on, served from a
- * resident pre-shifted copy; a fingerprint collision therefore costs a cache miss, never a wrong result,
- * and nothing the caller can observe is retained.  Caches are per calling thread; their device memory is
- * charged to one process-wide budget (REEF_MSM_KEY_CACHE_MB, default 16384); on an allocation failure the
- * thread's cache is emptied and the call is served uncached.  REEF_MSM_KEY_CACHE=0 turns the cache off.) */
+ * CONFIRMED byte for byte against a retained device copy, and, from its third call in the process on, served
+ * from a resident pre-shifted copy; a fingerprint collision therefore costs a cache miss, never a wrong result,
+ * and nothing the caller can observe is retained.  The table of resident keys is one per process (at most 16
+ * keys, REEF_MSM_KEY_CACHE_MB of device memory, default 16384): the key is built once, whichever threads call --
+ * nova-snark reaches these symbols from the prover thread and from rayon workers, src/backend/framework.rs:110,
+ * 668,695 -- and each calling thread serves it through its own stream and workspace on the shared tables.  On an
+ * allocation failure the table is emptied and the call is served uncached.  REEF_MSM_KEY_CACHE=0 turns it off.) */
 void mult_pippenger_pallas(reef_jacobian *out, const reef_affine *points, size_t npoints,
                            const reef_fe *scalars, bool is_mont);
 void mult_pippenger_vesta(reef_jacobian *out, const reef_affine *points, size_t npoints,
                           const reef_fe *scalars, bool is_mont);
+/* What the drop-in symbols' process-wide key table holds (tests, diagnostics): entries nominated, keys with a resident copy,
+ * device bytes charged to the budget, and counters since the process started -- resident copies built, calls served from
+ * one, per-thread clones made.  reef_key_cache_clear drops every entry (threads let go of their clones at their next call). */
+typedef struct {
+    uint64_t entries, resident_keys, resident_bytes, builds, hits, clones, reserved[2];
+} reef_key_cache_stats;
+void reef_key_cache_info(reef_key_cache_stats *out);
+void reef_key_cache_clear(void);
 
 /* ---------------------------------------------------------------------------------------------
  * (2) Resident-key handle API.
@@ -331,6 +351,25 @@ void reef_device_free(void *p);
 reef_status reef_memcpy(void *dst, const void *src, size_t bytes, int dst_loc, int src_loc);
 const char *reef_last_error(void);                     /* thread-local message of the last failure */
 const char *reef_version(void);
+uint32_t reef_abi_version(void);                       /* REEF_ABI_VERSION of the library that was loaded */
+/* Process-wide runtime settings, for embedders that want them explicit.  The HIP runtime maps a process's streams onto
+ * GPU_MAX_HW_QUEUES hardware queues (4 unless set) and streams that share a queue run in turn; concurrent callers of this
+ * library (the three arguments of the final SNARK, rayon workers: src/backend/framework.rs:695-721) want 8.  The variable is
+ * read at the process's FIRST HIP call, so this must run before it.  By default (opt-out) the library puts 8 into the
+ * environment when it is loaded unless the variable is already set or REEF_MSM_HW_QUEUES=0; this call makes the choice
+ * explicit: hw_queues > 0 asks for that many, < 0 withdraws the library's own setting, 0 changes nothing.  A value the user
+ * exported is never overwritten.  info (may be NULL) reports what the environment holds and who put it there. */
+typedef struct {
+    int32_t hw_queues;
+    uint32_t reserved[7];
+} reef_runtime_opts;
+typedef struct {
+    int32_t hw_queues_env;             /* GPU_MAX_HW_QUEUES as the environment holds it now (0: unset) */
+    int32_t hw_queues_set_by_library;  /* the value this library put there (0: it did not) */
+    uint32_t abi_version;
+    uint32_t reserved;
+} reef_runtime_info;
+reef_status reef_runtime_init(const reef_runtime_opts *opts /* may be NULL */, reef_runtime_info *info /* may be NULL */);
 
 /* One MSM split by Pippenger window across `world` GPUs (north_star): every GPU holds
  * the whole key and receives all scalars, but accumulates only the windows w = rank (mod world), so

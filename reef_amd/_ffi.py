@@ -35,6 +35,21 @@ class MsmOpts(ctypes.Structure):
                 ("device", c_int32), ("reserved", c_uint32 * 3)]
 
 
+class RuntimeOpts(ctypes.Structure):
+    _fields_ = [("hw_queues", c_int32), ("reserved", c_uint32 * 7)]
+
+
+class RuntimeInfo(ctypes.Structure):
+    _fields_ = [("hw_queues_env", c_int32), ("hw_queues_set_by_library", c_int32), ("abi_version", c_uint32), ("reserved", c_uint32)]
+
+
+class KeyCacheStats(ctypes.Structure):
+    _fields_ = [(n, c_uint64) for n in ("entries", "resident_keys", "resident_bytes", "builds", "hits", "clones")] + [("reserved", c_uint64 * 2)]
+
+
+ABI_VERSION = 4     # REEF_ABI_VERSION of include/reef_msm.h this binding was written against
+
+
 def build(force: bool = False, jobs: int = 3) -> str:
     """Compile every HIP source for gfx950 (hipcc cross-compiles without a GPU)."""
     cmd = ["make", "-C", CSRC, f"-j{jobs}"]
@@ -85,6 +100,10 @@ def load() -> ctypes.CDLL:
         "reef_memcpy": (c_int, [vp, vp, c_size_t, c_int, c_int]),
         "reef_last_error": (c_char_p, []),
         "reef_version": (c_char_p, []),
+        "reef_abi_version": (c_uint32, []),
+        "reef_key_cache_info": (None, [POINTER(KeyCacheStats)]),
+        "reef_key_cache_clear": (None, []),
+        "reef_runtime_init": (c_int, [POINTER(RuntimeOpts), POINTER(RuntimeInfo)]),
         "reef_msm_ctx_last_timing": (c_int, [vp, POINTER(c_float), POINTER(c_float)]),
         "reef_msm_ctx_enable_timing": (c_int, [vp, c_int]),
         "reef_msm_ctx_set_window_split": (c_int, [vp, c_uint32, c_uint32]),
@@ -117,6 +136,8 @@ def load() -> ctypes.CDLL:
         fn = getattr(lib, name)  # AttributeError if the ABI lost a symbol: fail loudly
         fn.restype = res
         fn.argtypes = args
+    if lib.reef_abi_version() != ABI_VERSION:
+        raise RuntimeError(f"{LIB_PATH} has ABI version {lib.reef_abi_version()}, this binding expects {ABI_VERSION}: rebuild")
     _lib = lib
     return lib
 

@@ -30,14 +30,28 @@ void set_error(const char *fmt, ...) {
 // a queue run one after the other.  One caller thread is a context stream plus its scratch stream: with the three arguments of
 // the final SNARK issued at once that is more than four, and their latency-bound rounds queue up behind each
 // other -- 8.3 ms against 6.4 ms with eight queues for cfg3, 4 threads of IPA rounds 1.95x against 2.55x one thread
-// (tools/time_concurrent_ipa.py).  The variable is read when the runtime initialises, i.e. at the process's first HIP call:
-// set here, when the library is loaded, unless the user has set it (REEF_MSM_HW_QUEUES=<n> asks for n, =0 leaves it alone).
+// (tools/time_concurrent_ipa.py).  The variable is read when the runtime initialises, i.e. at the process's first HIP call.
+// Two ways in: an embedder calls reef_runtime_init() before its first HIP call (explicit, reported back), or -- the opt-out
+// default -- the library asks for 8 when it is loaded unless the user has set the variable (REEF_MSM_HW_QUEUES=<n> asks for n,
+// =0 leaves the runtime alone).  Either way a value the user exported wins, and REEF_MSM_LOG=1 says on stderr what was done.
 namespace {
+std::atomic<int> g_hw_queues_asked{0};     // what this library put into the environment (0: nothing)
+static int ask_hw_queues(int n) {
+    if (n <= 0) return 0;
+    if (getenv("GPU_MAX_HW_QUEUES")) return 0;          // the user's (or an earlier call's) value stands
+    char buf[16];
+    snprintf(buf, sizeof buf, "%d", n);
+    setenv("GPU_MAX_HW_QUEUES", buf, 0);
+    g_hw_queues_asked.store(n);
+    if (const char *l = getenv("REEF_MSM_LOG"))
+        if (atoi(l) > 0) fprintf(stderr, "libreef_msm: GPU_MAX_HW_QUEUES=%d set for this process (REEF_MSM_HW_QUEUES=0 or reef_runtime_init opts out)\n", n);
+    return n;
+}
 struct HwQueues {
     HwQueues() {
         const char *o = getenv("REEF_MSM_HW_QUEUES");
         if (o && o[0] == '0' && o[1] == 0) return;
-        setenv("GPU_MAX_HW_QUEUES", (o && *o) ? o : "8", 0);
+        ask_hw_queues((o && *o) ? atoi(o) : 8);
     }
 } g_hw_queues;
 }  // namespace
@@ -100,7 +114,26 @@ template <class F> static reef_status guarded(F &&f) {
 extern "C" {
 
 const char *reef_last_error(void) { return g_err; }
-const char *reef_version(void) { return "reef_msm 0.1 (gfx950)"; }
+const char *reef_version(void) { return "reef_msm 0.4 (gfx950)"; }
+uint32_t reef_abi_version(void) { return REEF_ABI_VERSION; }
+reef_status reef_runtime_init(const reef_runtime_opts *opts, reef_runtime_info *info) {
+    if (opts && opts->hw_queues > 0) {
+        // an explicit request replaces what the library constructor put there (never what the user exported)
+        if (g_hw_queues_asked.load() > 0) unsetenv("GPU_MAX_HW_QUEUES");
+        ask_hw_queues(opts->hw_queues);
+    } else if (opts && opts->hw_queues < 0 && g_hw_queues_asked.load() > 0) {
+        unsetenv("GPU_MAX_HW_QUEUES");               // leave the runtime alone: take the constructor's value back
+        g_hw_queues_asked.store(0);
+    }
+    if (info) {
+        const char *e = getenv("GPU_MAX_HW_QUEUES");
+        info->hw_queues_env = e ? atoi(e) : 0;
+        info->hw_queues_set_by_library = g_hw_queues_asked.load();
+        info->abi_version = REEF_ABI_VERSION;
+        info->reserved = 0;
+    }
+    return REEF_OK;
+}
 
 int reef_device_count(void) {
     int n = 0;
@@ -353,26 +386,44 @@ void reef_shake256(const uint8_t *in, size_t in_len, uint8_t *out, size_t out_le
 namespace {
 // A commitment key that keeps coming back (Reef commits to the same generators in every folding step,
 // src/backend/framework.rs:297-303) is recognised by the fingerprint of its uploaded bytes; from its
-// third appearance on the call runs on a resident pre-shifted copy (the bases still cross PCIe, but
-// import, the plain-key pipeline and the host-side window combine are skipped).  Keys seen once -- the
-// folded generators of an IPA round -- never get a resident copy.  REEF_MSM_KEY_CACHE=0 turns it off.
+// third appearance on -- in the PROCESS, whichever threads made the calls -- the call runs on a resident
+// pre-shifted copy (the bases still cross PCIe, but import, the plain-key pipeline and the host-side window
+// combine are skipped).  Keys seen once -- the folded generators of an IPA round -- never get a resident copy.
+// REEF_MSM_KEY_CACHE=0 turns it off.
 //
 // The fingerprint only NOMINATES an entry: a hit is confirmed by comparing the uploaded bytes with the
 // copy retained next to the resident key (one more pass over two buffers), so a fingerprint collision
-// costs a miss, never a wrong commitment.  Caches are per calling thread (no lock on the MSM path), their
-// device memory is charged to one process-wide budget (REEF_MSM_KEY_CACHE_MB, default 16384 = 16 GiB of the
-// 288 GB), and an allocation failure anywhere on this path empties the thread's cache and retries once on
+// costs a miss, never a wrong commitment.
+//
+// Since round 4 the table of resident keys is ONE per process (nova-snark reaches this symbol from the prover thread
+// and from rayon workers, src/backend/framework.rs:110,668,695): a key is built once, by the thread that brings its
+// second appearance, and every caller thread serves it through a clone of its own -- a HIP stream and a workspace on the
+// shared, read-only tables (reef_msm_ctx_clone).  16 callers cost one warm-up and one copy of the key (round 3: one of each
+// per thread).  The table lock is held for the lookup only, never across HIP work; while a key is being built the other
+// threads serve it on the plain path.  Device memory is charged to one budget (REEF_MSM_KEY_CACHE_MB, default 16384 = 16 GiB
+// of the 288 GB); an allocation failure anywhere on this path empties the table and the thread's clones and retries once on
 // the plain, uncached path before the symbol gives up.
-struct KeyCacheEntry {
+struct SharedKey {
+    int curve = 0, device = 0;
     uint64_t h[2] = {0, 0};
     size_t n = 0;
-    reef_msm_ctx *resident = nullptr;
+    reef_msm_ctx *master = nullptr;    // owns the reference on the pre-shifted tables the clones share
     void *raw = nullptr;               // device copy of the bytes the resident key was built from
     size_t charged = 0;                // bytes charged to the process-wide budget
-    uint64_t last_use = 0;
+    std::atomic<uint64_t> last_use{0};
+    std::atomic<int> state{0};         // 0 nominated (seen, no copy), 1 being built, 2 resident, 3 evicted, 4 not worth another try
+    uint32_t seen = 1;                 // under the table lock
+    ~SharedKey();
 };
 std::atomic<size_t> g_cache_bytes{0};
-std::atomic<bool> g_process_exiting{false};   // TLS destructors of the main thread run after HIP may be gone
+std::atomic<uint64_t> g_cache_builds{0}, g_cache_hits{0}, g_cache_clones{0};
+std::atomic<bool> g_process_exiting{false};   // destructors that run at process teardown must not touch HIP: it may be gone
+SharedKey::~SharedKey() {
+    if (g_process_exiting.load()) return;          // the driver reclaims everything
+    reef_msm_ctx_destroy(master);
+    if (raw) reef_device_free(raw);
+    g_cache_bytes -= charged;
+}
 static size_t cache_budget() {
     static const size_t b = [] {
         const char *e = getenv("REEF_MSM_KEY_CACHE_MB");
@@ -380,109 +431,186 @@ static size_t cache_budget() {
     }();
     return b;
 }
-static void entry_drop(KeyCacheEntry &e) {
-    reef_msm_ctx_destroy(e.resident);
-    if (e.raw) reef_device_free(e.raw);
-    g_cache_bytes -= e.charged;
-    e.resident = nullptr; e.raw = nullptr; e.charged = 0;
+constexpr size_t KEY_CACHE_MIN_POINTS = 1024, KEY_TABLE_ENTRIES = 16, LANES_PER_THREAD = 6;
+struct KeyTable {
+    std::mutex mu;
+    std::vector<std::shared_ptr<SharedKey>> keys;
+    std::atomic<uint64_t> tick{0};
+    // every entry leaves the table; a key lives on until the last thread that holds a clone of it has let go
+    void clear() {
+        std::lock_guard<std::mutex> lk(mu);
+        for (auto &k : keys) k->state.store(3);
+        keys.clear();
+    }
+};
+static KeyTable &key_table() {
+    static KeyTable *t = new KeyTable();            // never destroyed: static destructors run after HIP may be gone
+    return *t;
 }
+struct Lane {                                      // one caller thread's handle on a resident key
+    std::shared_ptr<SharedKey> key;
+    reef_msm_ctx *clone = nullptr;
+};
 struct TlsCtx {
     reef_msm_ctx *ctx[2] = {nullptr, nullptr};
+    int ctx_dev[2] = {-1, -1};
     void *stage = nullptr;
     size_t stage_cap = 0;
-    std::vector<KeyCacheEntry> cache[2];
-    uint64_t tick = 0;
-    void drop_cache() {
-        for (auto &v : cache) {
-            for (auto &e : v) entry_drop(e);
-            v.clear();
-        }
+    int stage_dev = -1;
+    std::vector<Lane> lanes;
+    void drop_lane(size_t i) {
+        reef_msm_ctx_destroy(lanes[i].clone);
+        lanes.erase(lanes.begin() + i);
+    }
+    void drop_lanes() {
+        while (!lanes.empty()) drop_lane(lanes.size() - 1);
+    }
+    void drop_stage() {
+        if (stage) reef_device_free(stage);
+        stage = nullptr; stage_cap = 0; stage_dev = -1;
     }
     ~TlsCtx() {
-        if (g_process_exiting.load()) return;          // process teardown: the driver reclaims everything
+        if (g_process_exiting.load()) {            // process teardown: leak, never call into HIP
+            new std::vector<Lane>(std::move(lanes));
+            return;
+        }
         for (auto *c : ctx) reef_msm_ctx_destroy(c);
-        drop_cache();
-        if (stage) reef_device_free(stage);
+        drop_lanes();
+        drop_stage();
     }
 };
 thread_local TlsCtx g_tls;
-constexpr size_t KEY_CACHE_MIN_POINTS = 1024, KEY_CACHE_ENTRIES = 6;
 
 static reef_status pippenger_plain(int curve, reef_jacobian *out, const reef_affine *points, size_t npoints, int points_loc, const reef_fe *scalars,
                                    bool is_mont) {
     reef_msm_ctx *&c = g_tls.ctx[curve];
-    if (!c) REEF_TRY(reef_msm_ctx_create(&c, curve, points, npoints, points_loc, nullptr));
-    else REEF_TRY(vt(curve)->ctx_rekey(c->impl, points, npoints, points_loc));
+    int dev = 0;
+    REEF_HIP_TRY(hipGetDevice(&dev));
+    if (c && g_tls.ctx_dev[curve] != dev) { reef_msm_ctx_destroy(c); c = nullptr; }   // the caller moved to another GPU
+    if (!c) {
+        REEF_TRY(reef_msm_ctx_create(&c, curve, points, npoints, points_loc, nullptr));
+        g_tls.ctx_dev[curve] = dev;
+    } else {
+        REEF_TRY(vt(curve)->ctx_rekey(c->impl, points, npoints, points_loc));
+    }
     return reef_msm(c, scalars, npoints, REEF_HOST, is_mont, out, REEF_HOST);
+}
+
+// The resident copy of a key whose second appearance this thread brought: raw bytes + pre-shifted tables.  Failure is never
+// fatal -- the key keeps being served on the plain path.
+static void build_resident(const std::shared_ptr<SharedKey> &k, const reef_affine *staged) {
+    const size_t bytes = k->n * sizeof(reef_affine);
+    uint32_t T = 1;
+    (void)reef_msm_plan_for(k->n, 0, 1, nullptr, nullptr, nullptr, &T);
+    const size_t cost = bytes * ((size_t)T + 1);       // T pre-shifted tables + the raw copy
+    int done = 4;
+    if (g_cache_bytes.load() + cost <= cache_budget()) {
+        reef_msm_opts o = {};
+        o.bucket_groups = 1;
+        o.byte_tables = 2;                             // never for a key the caller did not create: 256 KiB per point would dwarf the budget
+        o.device = k->device;
+        void *raw = reef_device_alloc(bytes);
+        reef_msm_ctx *master = nullptr;
+        if (raw && reef_memcpy(raw, staged, bytes, REEF_DEVICE, REEF_DEVICE) == REEF_OK &&
+            reef_msm_ctx_create(&master, k->curve, staged, k->n, REEF_DEVICE, &o) == REEF_OK) {
+            k->raw = raw;
+            k->master = master;
+            k->charged = cost;
+            g_cache_bytes += cost;
+            g_cache_builds += 1;
+            done = 2;
+        } else if (raw) {
+            reef_device_free(raw);
+        }
+    }
+    int expect = 1;                                    // an entry evicted meanwhile (state 3) stays evicted
+    k->state.compare_exchange_strong(expect, done, std::memory_order_release);
 }
 
 static reef_status pippenger_cached(int curve, reef_jacobian *out, const reef_affine *points, size_t npoints, const reef_fe *scalars, bool is_mont) {
     const size_t bytes = npoints * sizeof(reef_affine);
-    if (bytes > g_tls.stage_cap) {
-        if (g_tls.stage) reef_device_free(g_tls.stage);
+    int dev = 0;
+    REEF_HIP_TRY(hipGetDevice(&dev));
+    if (bytes > g_tls.stage_cap || g_tls.stage_dev != dev) {
+        g_tls.drop_stage();
         g_tls.stage = reef_device_alloc(bytes + bytes / 8);
-        g_tls.stage_cap = g_tls.stage ? bytes + bytes / 8 : 0;
         if (!g_tls.stage) return REEF_ERR_OOM;
+        g_tls.stage_cap = bytes + bytes / 8;
+        g_tls.stage_dev = dev;
     }
     REEF_TRY(reef_memcpy(g_tls.stage, points, bytes, REEF_DEVICE, REEF_HOST));
     uint64_t h[2];
     REEF_TRY(vt(curve)->fingerprint(g_tls.stage, bytes, h));
-    auto &cache = g_tls.cache[curve];
-    KeyCacheEntry *hit = nullptr;
-    for (auto &e : cache)
-        if (e.n == npoints && e.h[0] == h[0] && e.h[1] == h[1]) hit = &e;
-    const uint64_t now = ++g_tls.tick;
-    if (hit && hit->resident) {
-        int same = 0;
-        REEF_TRY(vt(curve)->bytes_equal(g_tls.stage, hit->raw, bytes, &same));
-        if (same) {
-            hit->last_use = now;
-            return reef_msm(hit->resident, scalars, npoints, REEF_HOST, is_mont, out, REEF_HOST);
-        }
-        hit = nullptr;                                 // a fingerprint collision: this is another key, serve it uncached
-        return pippenger_plain(curve, out, (const reef_affine *)g_tls.stage, npoints, REEF_DEVICE, scalars, is_mont);
-    }
     const reef_affine *staged = (const reef_affine *)g_tls.stage;
-    REEF_TRY(pippenger_plain(curve, out, staged, npoints, REEF_DEVICE, scalars, is_mont));
-    if (hit) {                                         // second appearance: worth a resident pre-shifted copy, if the budget allows
-        hit->last_use = now;
-        uint32_t T = 1;
-        (void)reef_msm_plan_for(npoints, 0, 1, nullptr, nullptr, nullptr, &T);
-        const size_t cost = bytes * ((size_t)T + 1);   // T pre-shifted tables + the raw copy
-        if (g_cache_bytes.load() + cost > cache_budget()) return REEF_OK;
-        reef_msm_opts o = {};
-        o.bucket_groups = 1;
-        o.byte_tables = 2;                             // never for a key the caller did not create: 256 KiB per point would dwarf the budget charged above
-        o.device = -1;
-        void *raw = reef_device_alloc(bytes);
-        if (!raw) return REEF_OK;                       // no memory for a copy: keep serving this key uncached
-        if (reef_memcpy(raw, g_tls.stage, bytes, REEF_DEVICE, REEF_DEVICE) != REEF_OK ||
-            reef_msm_ctx_create(&hit->resident, curve, staged, npoints, REEF_DEVICE, &o) != REEF_OK) {
-            reef_device_free(raw);
-            hit->resident = nullptr;
-            return REEF_OK;
+    for (size_t i = g_tls.lanes.size(); i-- > 0;)      // clones of keys the table has let go: give their memory back
+        if (g_tls.lanes[i].key->state.load(std::memory_order_acquire) == 3) g_tls.drop_lane(i);
+
+    KeyTable &tab = key_table();
+    std::shared_ptr<SharedKey> k;
+    bool builder = false;
+    {
+        std::lock_guard<std::mutex> lk(tab.mu);
+        const uint64_t now = ++tab.tick;
+        for (auto &e : tab.keys)
+            if (e->curve == curve && e->device == dev && e->n == npoints && e->h[0] == h[0] && e->h[1] == h[1]) k = e;
+        if (k) {
+            k->last_use.store(now);
+            k->seen += 1;
+            int expect = 0;
+            builder = k->seen >= 2 && k->state.compare_exchange_strong(expect, 1);   // second appearance: worth a resident copy
+        } else {
+            if (tab.keys.size() >= KEY_TABLE_ENTRIES) {  // forget the least recently used key; keys seen once (no resident copy) go first
+                size_t lru = tab.keys.size();
+                for (int pass = 0; pass < 2 && lru == tab.keys.size(); ++pass)
+                    for (size_t i = 0; i < tab.keys.size(); ++i) {
+                        const int st = tab.keys[i]->state.load();
+                        if (st == 1 || (pass == 0 && st == 2)) continue;              // never the one being built
+                        if (lru == tab.keys.size() || tab.keys[i]->last_use.load() < tab.keys[lru]->last_use.load()) lru = i;
+                    }
+                if (lru < tab.keys.size()) {
+                    tab.keys[lru]->state.store(3);
+                    tab.keys.erase(tab.keys.begin() + lru);
+                }
+            }
+            if (tab.keys.size() < KEY_TABLE_ENTRIES) {
+                auto e = std::make_shared<SharedKey>();
+                e->curve = curve; e->device = dev; e->n = npoints; e->h[0] = h[0]; e->h[1] = h[1];
+                e->last_use.store(now);
+                tab.keys.push_back(e);
+            }
         }
-        hit->raw = raw;
-        hit->charged = cost;
-        g_cache_bytes += cost;
-        return REEF_OK;
     }
-    if (cache.size() >= KEY_CACHE_ENTRIES) {           // forget the least recently used key
-        size_t lru = cache.size();                      // keys seen once (no resident copy) go first
-        for (size_t i = 0; i < cache.size(); ++i)
-            if (!cache[i].resident && (lru == cache.size() || cache[i].last_use < cache[lru].last_use)) lru = i;
-        if (lru == cache.size()) {
-            lru = 0;
-            for (size_t i = 1; i < cache.size(); ++i)
-                if (cache[i].last_use < cache[lru].last_use) lru = i;
+    if (k && !builder && k->state.load(std::memory_order_acquire) == 2) {
+        int same = 0;
+        REEF_TRY(vt(curve)->bytes_equal(g_tls.stage, k->raw, bytes, &same));
+        if (same) {
+            Lane *lane = nullptr;
+            for (auto &l : g_tls.lanes)
+                if (l.key == k) lane = &l;
+            if (!lane) {
+                if (g_tls.lanes.size() >= LANES_PER_THREAD) g_tls.drop_lane(0);      // oldest first
+                reef_msm_ctx *c = nullptr;
+                REEF_TRY(reef_msm_ctx_clone(&c, k->master));
+                g_cache_clones += 1;
+                g_tls.lanes.push_back(Lane{k, c});
+                lane = &g_tls.lanes.back();
+            } else if (lane != &g_tls.lanes.back()) {  // keep the lanes in order of use
+                Lane l = *lane;
+                g_tls.lanes.erase(g_tls.lanes.begin() + (lane - &g_tls.lanes[0]));
+                g_tls.lanes.push_back(l);
+                lane = &g_tls.lanes.back();
+            }
+            g_cache_hits += 1;
+            return reef_msm(lane->clone, scalars, npoints, REEF_HOST, is_mont, out, REEF_HOST);
         }
-        entry_drop(cache[lru]);
-        cache.erase(cache.begin() + lru);
+        // a fingerprint collision: this is another key, serve it uncached
     }
-    KeyCacheEntry e;
-    e.h[0] = h[0]; e.h[1] = h[1]; e.n = npoints; e.last_use = now;
-    cache.push_back(e);
-    return REEF_OK;
+    const reef_status st = pippenger_plain(curve, out, staged, npoints, REEF_DEVICE, scalars, is_mont);
+    if (builder) {
+        if (st == REEF_OK) build_resident(k, staged);
+        else { int expect = 1; k->state.compare_exchange_strong(expect, 0); }
+    }
+    return st;
 }
 
 static reef_status pippenger_try(int curve, reef_jacobian *out, const reef_affine *points, size_t npoints, const reef_fe *scalars, bool is_mont) {
@@ -492,8 +620,9 @@ static reef_status pippenger_try(int curve, reef_jacobian *out, const reef_affin
     reef_status st = (!cache_on || npoints < KEY_CACHE_MIN_POINTS) ? pippenger_plain(curve, out, points, npoints, REEF_HOST, scalars, is_mont)
                                                                      : pippenger_cached(curve, out, points, npoints, scalars, is_mont);
     if (st == REEF_ERR_OOM) {                           // give the cache's memory back and serve the call uncached
-        g_tls.drop_cache();
-        if (g_tls.stage) { reef_device_free(g_tls.stage); g_tls.stage = nullptr; g_tls.stage_cap = 0; }
+        key_table().clear();
+        g_tls.drop_lanes();
+        g_tls.drop_stage();
         st = pippenger_plain(curve, out, points, npoints, REEF_HOST, scalars, is_mont);
     }
     return st;
@@ -506,6 +635,20 @@ static void pippenger(int curve, reef_jacobian *out, const reef_affine *points, 
     }
 }
 }  // namespace
+
+void reef_key_cache_info(reef_key_cache_stats *out) {
+    if (!out) return;
+    KeyTable &tab = key_table();
+    std::lock_guard<std::mutex> lk(tab.mu);
+    out->entries = tab.keys.size();
+    out->resident_keys = 0;
+    for (auto &k : tab.keys) out->resident_keys += k->state.load() == 2;
+    out->resident_bytes = g_cache_bytes.load();
+    out->builds = g_cache_builds.load();
+    out->hits = g_cache_hits.load();
+    out->clones = g_cache_clones.load();
+}
+void reef_key_cache_clear(void) { key_table().clear(); }
 
 void mult_pippenger_pallas(reef_jacobian *out, const reef_affine *points, size_t npoints, const reef_fe *scalars, bool is_mont) {
     pippenger(REEF_PALLAS, out, points, npoints, scalars, is_mont);

@@ -12,6 +12,23 @@ def test_library_present_and_loads():
     assert os.path.exists(_ffi.LIB_PATH), "run __graft_entry__.build() first"
     lib = _ffi.load()
     assert lib.reef_version().startswith(b"reef_msm")
+    import re
+    header = int(re.search(r"#define REEF_ABI_VERSION (\d+)", open(_ffi.HEADER).read()).group(1))
+    assert lib.reef_abi_version() == header == _ffi.ABI_VERSION          # header, binding and binary agree
+
+
+def test_runtime_init_reports_who_set_the_hardware_queues():
+    """reef_runtime_init makes the GPU_MAX_HW_QUEUES choice explicit: it never overwrites a value the user exported and
+    reports what the environment holds; pure host logic, no HIP call."""
+    lib = _ffi.load()
+    info = _ffi.RuntimeInfo()
+    assert lib.reef_runtime_init(None, ctypes.byref(info)) == 0
+    assert info.abi_version == _ffi.ABI_VERSION
+    assert info.hw_queues_env == int(os.environ.get("GPU_MAX_HW_QUEUES", "0"))   # reef_amd._ffi (or the user) exported it before the load
+    assert info.hw_queues_set_by_library == 0                                  # so the library's constructor left it alone
+    opts = _ffi.RuntimeOpts(hw_queues=16)
+    assert lib.reef_runtime_init(ctypes.byref(opts), ctypes.byref(info)) == 0
+    assert info.hw_queues_env == int(os.environ.get("GPU_MAX_HW_QUEUES", "0")) and info.hw_queues_set_by_library == 0
 
 
 def test_exports_every_declared_symbol():
@@ -24,6 +41,7 @@ def test_exports_every_declared_symbol():
 
 def test_struct_sizes_match_header():
     assert ctypes.sizeof(_ffi.MsmOpts) == 32
+    assert ctypes.sizeof(_ffi.RuntimeOpts) == 32 and ctypes.sizeof(_ffi.RuntimeInfo) == 16
 
 
 def test_plan_for_host_logic():

@@ -1,0 +1,110 @@
+"""The one seam an unmodified Reef reaches -- pasta-msm's `mult_pippenger_pallas/vesta` -- under the callers it really has:
+nova-snark calls it from the main prover thread and from rayon workers (SURVEY.md 8b "Threading";
+src/backend/framework.rs:110, 668, 695), so several threads are inside the symbol at once, on the same commitment key and on
+different ones, and worker threads come and go.  Every result is compared with the C oracle (oracle/pasta_ref.c)."""
+import ctypes
+import threading
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+SIZES = (128, 3000, 24918, 1 << 16)          # below the cache threshold, small, cfg3's W key length (replay_shapes.json), Reef's 2^16
+
+
+def cache_info():
+    from reef_amd import _ffi
+    st = _ffi.KeyCacheStats()
+    _ffi.load().reef_key_cache_info(ctypes.byref(st))
+    return {n: getattr(st, n) for n, _ in st._fields_ if n != "reserved"}
+
+
+def run_threads(nthreads, fn):
+    errs = []
+
+    def wrap(t):
+        try:
+            fn(t)
+        except BaseException as e:          # an assertion in a worker must fail the test
+            errs.append((t, repr(e)))
+    ts = [threading.Thread(target=wrap, args=(t,)) for t in range(nthreads)]
+    [t.start() for t in ts]
+    [t.join() for t in ts]
+    assert not errs, errs[:3]
+
+
+@pytest.fixture(scope="module")
+def cases(cref):
+    """Per curve and size: one key, four scalar vectors (uniform and witness-like) and the oracle's compressed commitments."""
+    out = {}
+    for cid in (0, 1):
+        for n in SIZES:
+            bases = cref.gen_bases_ap(cid, 7000 + 31 * n % 997 + cid, 3, n)
+            bases[n // 3] = 0                                                  # an identity base inside every key
+            scal = [cref.gen_scalars(cid, 900 + 7 * j + cid, n, kind=j % 2) for j in range(4)]
+            want = [cref.compress(cid, cref.msm_pippenger(cid, bases, s, threads=8)) for s in scal]
+            out[(cid, n)] = (bases, scal, want)
+    return out
+
+
+def test_eight_threads_share_one_key(gpu_lib, cref, cases):
+    """Eight threads at once on the SAME key, for every size and both curves; the threads are started and joined three times so
+    that thread-local state (streams, workspaces, clones of the resident key) is torn down and rebuilt while the process-wide
+    table lives on.  One resident copy per key is built, whatever the number of callers."""
+    from reef_amd import msm
+    gpu_lib.reef_key_cache_clear()
+    before = cache_info()
+    for cid in (0, 1):
+        for n in SIZES:
+            bases, scal, want = cases[(cid, n)]
+            for generation in range(3):
+                def work(t):
+                    for rep in range(4):
+                        j = (t + rep + generation) % 4
+                        got = msm.compress(cid, msm.mult_pippenger(cid, bases, scal[j]))
+                        assert got == want[j], (cid, n, generation, t, rep)
+                run_threads(8, work)
+    after = cache_info()
+    cached_keys = 2 * sum(1 for n in SIZES if n >= 1024)
+    assert after["builds"] - before["builds"] == cached_keys, (before, after)       # one build per key, not one per thread
+    assert after["resident_keys"] == cached_keys
+    assert after["hits"] - before["hits"] >= cached_keys * 2 * 8 * 4, (before, after)   # at least every call of generations 1 and 2
+    per_key = {n: 64 * n * (msm.plan_for(n, bucket_groups=1)["tables"] + 1) for n in SIZES if n >= 1024}
+    assert after["resident_bytes"] == 2 * sum(per_key.values())                     # one copy of each key, 16 callers or not
+
+
+def test_threads_on_different_keys_and_curves_at_once(gpu_lib, cref, cases):
+    """Eight threads inside the symbol at once, each on its own (curve, size) -- both curves, all four sizes -- then every thread
+    walks through all of them; more distinct keys in flight than one thread keeps clones of."""
+    from reef_amd import msm
+    combos = [(cid, n) for cid in (0, 1) for n in SIZES]
+    for generation in range(2):
+        def work(t):
+            for step in range(len(combos)):
+                cid, n = combos[(t + step) % len(combos)]
+                bases, scal, want = cases[(cid, n)]
+                j = (t + step) % 4
+                assert msm.compress(cid, msm.mult_pippenger(cid, bases, scal[j])) == want[j], (generation, t, cid, n)
+        run_threads(8, work)
+
+
+def test_table_turnover_under_concurrency(gpu_lib, cref):
+    """More keys than the process-wide table has entries (16), revisited by four threads at once: entries are evicted while other
+    threads still hold clones of them; results stay right and the evicted keys' memory is given back."""
+    from reef_amd import msm
+    cid, n = 0, 1500
+    keys = [cref.gen_bases_ap(cid, 4000 + 17 * k, 5, n) for k in range(20)]
+    sc = cref.gen_scalars(cid, 77, n)
+    want = [cref.compress(cid, cref.msm_pippenger(cid, kb, sc, threads=4)) for kb in keys]
+
+    def work(t):
+        for rnd in range(3):
+            for k in range(len(keys)):
+                kk = (k + 5 * t) % len(keys)
+                assert msm.compress(cid, msm.mult_pippenger(cid, keys[kk], sc)) == want[kk], (t, rnd, kk)
+    run_threads(4, work)
+    info = cache_info()
+    assert info["entries"] <= 16 and info["resident_keys"] <= 16
+    gpu_lib.reef_key_cache_clear()
+    msm.mult_pippenger(cid, keys[0], sc)            # this thread lets go of the clones it holds of evicted keys
+    assert cache_info()["entries"] == 1

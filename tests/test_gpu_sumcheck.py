@@ -345,6 +345,41 @@ def test_structured_pristine_table_vs_oracle(kind, ell, nq, fused, gpu_lib, monk
         assert sc.round_coeffs(1) == linear_mle_coeffs(t, e, ell, 1, q)
 
 
+@pytest.mark.parametrize("kind,ell,nq", [("hybrid", 10, 7), ("mixed", 9, 4)])
+def test_gen_eq_before_set_table_gives_the_same_step(kind, ell, nq, gpu_lib, monkeypatch):
+    """The results do not depend on the order of the calls (include/reef_msm.h 3b): gen_eq_table FIRST, then a structured table --
+    and a structured table that replaces an unstructured one after gen_eq_table -- give the coefficients of the reference order
+    (the sum of FL that constant rows need is taken in gen_eq_table whether or not a structure is known then: ADVICE r3)."""
+    from reef_amd.sumcheck import SumCheck
+    monkeypatch.setenv("REEF_SC_RANK1_MIN_POW", "1")
+    q = Q
+    rng = SplitMix64(ell * 977 + nq)
+    t = _structured_table(kind, ell, rng, q)
+    n = 1 << ell
+    dense = [uniform_scalar(rng, q) for _ in range(n)]         # no structure: every row is W
+    qs = [rng.next() % n for _ in range(nq)]
+    rs = [uniform_scalar(rng, q) for _ in range(nq + 1)]
+    last_q = [uniform_scalar(rng, q) for _ in range(ell)]
+    e = gen_eq_table(rs, qs, last_q, q)
+    for first in (None, dense):
+        with SumCheck("pallas", ell) as sc:
+            if first is not None:
+                sc.set_table(0, first)                          # the table present at gen_eq time is not the one the rounds run on
+            sc.gen_eq_table(rs, qs, last_q)
+            sc.set_table(0, t)
+            tt, ee = list(t), list(e)
+            g = sc.round_coeffs(1)
+            for i in range(1, ell + 1):
+                assert g == linear_mle_coeffs(tt, ee, ell, i, q), (kind, first is None, i)
+                r = uniform_scalar(rng, q)
+                linear_mle_fold(tt, ee, ell, i, r, q)
+                if i < ell:
+                    g = sc.fold_and_next_coeffs(i, r)
+                else:
+                    sc.fold(i, r)
+            assert sc.read(0, 1) == [tt[0]] and sc.read(1, 1) == [ee[0]]
+
+
 def test_structured_table_at_cfg4_shape(gpu_lib, monkeypatch):
     """2^24 entries shaped like the hybrid table of BASELINE's cfg4 (first half: a few transition rows, then one value; second
     half: DNA symbols, then zeros): the transcript of a folding step equals the one taken without the structure and the dense one."""
