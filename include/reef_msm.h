@@ -21,7 +21,7 @@
  * (it owns one HIP stream and one workspace); use one ctx (or clone) per concurrent caller.
  *
  * ABI changelog (reef_abi_version()):
- *   4  round 4: reef_runtime_init / reef_abi_version added; the drop-in symbols' key cache is one table per process
+ *   4  round 4: reef_runtime_init / reef_abi_version / reef_msm_ctx_attach / reef_key_cache_info added; the drop-in symbols' key cache is one table per process
  *      (clones per calling thread) instead of one cache per thread.
  *   3  round 3: reef_msm_opts.byte_tables = 0 changed meaning from "build the byte tables in the background" to "follow the
  *      process-wide policy: none unless REEF_MSM_WIDE=1" -- callers that pass zeroed opts no longer get the byte-table path
@@ -65,10 +65,10 @@ typedef enum {
  * Stateless: nothing is retained; bases are uploaded per call.  `is_mont` = scalars are in
  * Montgomery form (what the Rust wrapper passes).  abort()s on error.
  * ------------------------------------------------------------------------------------------- */
-/* (A key that keeps coming back is nominated by a non-cryptographic fingerprint of its uploaded bytes,
- * CONFIRMED byte for byte against a retained device copy, and, from its third call in the process on, served
- * from a resident pre-shifted copy; a fingerprint collision therefore costs a cache miss, never a wrong result,
- * and nothing the caller can observe is retained.  The table of resident keys is one per process (at most 16
+/* (A key that keeps coming back is nominated by non-cryptographic hashes of its bytes, CONFIRMED byte for byte
+ * against a retained copy while the GPU already works on the nominated key, and, from its third call in the
+ * process on, served from a resident pre-shifted copy; a hash collision therefore costs time, never a wrong
+ * result, and nothing the caller can observe is retained.  The table of resident keys is one per process (at most 16
  * keys, REEF_MSM_KEY_CACHE_MB of device memory, default 16384): the key is built once, whichever threads call --
  * nova-snark reaches these symbols from the prover thread and from rayon workers, src/backend/framework.rs:110,
  * 668,695 -- and each calling thread serves it through its own stream and workspace on the shared tables.  On an
@@ -79,9 +79,9 @@ void mult_pippenger_vesta(reef_jacobian *out, const reef_affine *points, size_t 
                           const reef_fe *scalars, bool is_mont);
 /* What the drop-in symbols' process-wide key table holds (tests, diagnostics): entries nominated, keys with a resident copy,
  * device bytes charged to the budget, and counters since the process started -- resident copies built, calls served from
- * one, per-thread clones made.  reef_key_cache_clear drops every entry (threads let go of their clones at their next call). */
+ * one, per-thread clones made, speculative calls whose bytes turned out to be another key's (served again on the plain path).  reef_key_cache_clear drops every entry (threads let go of their clones at their next call). */
 typedef struct {
-    uint64_t entries, resident_keys, resident_bytes, builds, hits, clones, reserved[2];
+    uint64_t entries, resident_keys, resident_bytes, builds, hits, clones, misspeculated, reserved;
 } reef_key_cache_stats;
 void reef_key_cache_info(reef_key_cache_stats *out);
 void reef_key_cache_clear(void);
@@ -124,6 +124,10 @@ reef_status reef_msm_ctx_set_bases(reef_msm_ctx *ctx, const reef_affine *bases, 
 /* A second handle on the same resident key with its own stream and workspace (for callers that
  * issue MSMs from several threads, e.g. nova's rayon workers inside ipa_pc). */
 reef_status reef_msm_ctx_clone(reef_msm_ctx **out, reef_msm_ctx *src);
+/* ctx becomes what a clone of src would be -- a handle on src's resident key -- but keeps its own stream and workspace (O(1);
+ * waits for the work already enqueued on ctx; same curve and device).  For callers with more keys than threads: one ctx per
+ * thread, attached to the key of the moment (what the drop-in symbols do per calling thread). */
+reef_status reef_msm_ctx_attach(reef_msm_ctx *ctx, reef_msm_ctx *src);
 void reef_msm_ctx_destroy(reef_msm_ctx *ctx);
 /* Block until everything enqueued on the ctx's stream has finished. */
 reef_status reef_msm_ctx_sync(reef_msm_ctx *ctx);

@@ -44,7 +44,7 @@ class RuntimeInfo(ctypes.Structure):
 
 
 class KeyCacheStats(ctypes.Structure):
-    _fields_ = [(n, c_uint64) for n in ("entries", "resident_keys", "resident_bytes", "builds", "hits", "clones")] + [("reserved", c_uint64 * 2)]
+    _fields_ = [(n, c_uint64) for n in ("entries", "resident_keys", "resident_bytes", "builds", "hits", "clones", "misspeculated", "reserved")]
 
 
 ABI_VERSION = 4     # REEF_ABI_VERSION of include/reef_msm.h this binding was written against
@@ -78,6 +78,7 @@ def load() -> ctypes.CDLL:
         "mult_pippenger_vesta": (None, [vp, vp, c_size_t, vp, c_bool]),
         "reef_msm_ctx_create": (c_int, [POINTER(vp), c_int, vp, c_size_t, c_int, POINTER(MsmOpts)]),
         "reef_msm_ctx_clone": (c_int, [POINTER(vp), vp]),
+        "reef_msm_ctx_attach": (c_int, [vp, vp]),
         "reef_msm_ctx_set_bases": (c_int, [vp, vp, c_size_t, c_int]),
         "reef_msm_ctx_destroy": (None, [vp]),
         "reef_msm_ctx_sync": (c_int, [vp]),

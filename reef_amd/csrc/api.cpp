@@ -179,6 +179,10 @@ reef_status reef_msm_ctx_set_bases(reef_msm_ctx *ctx, const reef_affine *bases, 
     if (!ctx || (n && !bases)) { set_error("null argument"); return REEF_ERR_ARG; }
     return vt(ctx->curve)->ctx_rekey(ctx->impl, bases, n, bases_loc);
 }
+reef_status reef_msm_ctx_attach(reef_msm_ctx *ctx, reef_msm_ctx *src) {
+    if (!ctx || !src || ctx->curve != src->curve) { set_error("attach: two contexts of the same curve"); return REEF_ERR_ARG; }
+    return vt(ctx->curve)->ctx_attach(ctx->impl, src->impl);
+}
 reef_status reef_msm_ctx_clone(reef_msm_ctx **out, reef_msm_ctx *src) {
     if (!out || !src) { set_error("null argument"); return REEF_ERR_ARG; }
     void *impl = nullptr;
@@ -381,44 +385,49 @@ reef_status reef_derive_generators(int curve, const uint8_t *label, size_t label
 void reef_shake256(const uint8_t *in, size_t in_len, uint8_t *out, size_t out_len) { reef::shake256(in, in_len, out, out_len); }
 
 // ---- pasta-msm drop-in symbols: stateless, abort on failure (the Rust side panics on error).
-// A per-thread context is kept so that repeated calls reuse the workspace; the bases are
-// re-uploaded on every call, as the reference semantics (nothing retained) require.
+// The bases are read on every call, as the reference semantics (nothing retained that the caller can observe) require.
 namespace {
 // A commitment key that keeps coming back (Reef commits to the same generators in every folding step,
-// src/backend/framework.rs:297-303) is recognised by the fingerprint of its uploaded bytes; from its
-// third appearance on -- in the PROCESS, whichever threads made the calls -- the call runs on a resident
-// pre-shifted copy (the bases still cross PCIe, but import, the plain-key pipeline and the host-side window
-// combine are skipped).  Keys seen once -- the folded generators of an IPA round -- never get a resident copy.
+// src/backend/framework.rs:297-303) is recognised by its bytes; from its third appearance on -- in the PROCESS, whichever
+// threads made the calls -- the call runs on a resident pre-shifted copy (import, the plain-key pipeline and the host-side
+// window combine are skipped).  Keys seen once -- the folded generators of an IPA round -- never get a resident copy.
 // REEF_MSM_KEY_CACHE=0 turns it off.
 //
-// The fingerprint only NOMINATES an entry: a hit is confirmed by comparing the uploaded bytes with the
-// copy retained next to the resident key (one more pass over two buffers), so a fingerprint collision
-// costs a miss, never a wrong commitment.
+// Hashes only NOMINATE an entry; a hit is CONFIRMED by comparing every byte the caller passed with the copy retained next to
+// the resident key, so a collision costs time, never a wrong commitment.  Round 4 made the confirmation free for Reef's sizes:
+// the caller's thread enqueues the MSM on the nominated key FIRST (speculation), compares the bytes while the GPU works --
+// on the host against a host copy for keys up to 2^17 points (8 MB: no base crosses PCIe on a hit), on the device on the same
+// stream for larger ones (an upload is faster there than a one-core memcmp) -- and takes the result only if they were equal;
+// otherwise the call is served again on the plain path.  One stream synchronisation per call instead of four.
 //
-// Since round 4 the table of resident keys is ONE per process (nova-snark reaches this symbol from the prover thread
-// and from rayon workers, src/backend/framework.rs:110,668,695): a key is built once, by the thread that brings its
-// second appearance, and every caller thread serves it through a clone of its own -- a HIP stream and a workspace on the
-// shared, read-only tables (reef_msm_ctx_clone).  16 callers cost one warm-up and one copy of the key (round 3: one of each
-// per thread).  The table lock is held for the lookup only, never across HIP work; while a key is being built the other
-// threads serve it on the plain path.  Device memory is charged to one budget (REEF_MSM_KEY_CACHE_MB, default 16384 = 16 GiB
-// of the 288 GB); an allocation failure anywhere on this path empties the table and the thread's clones and retries once on
-// the plain, uncached path before the symbol gives up.
+// The table of resident keys is ONE per process (round 4; nova-snark reaches this symbol from the prover thread and from
+// rayon workers, src/backend/framework.rs:110,668,695): a key is built once, by the thread that brings its second
+// appearance, and every caller thread serves it through a clone of its own -- a HIP stream and a workspace on the shared,
+// read-only tables (reef_msm_ctx_clone once, reef_msm_ctx_attach when the thread's next call is on another key: its
+// workspace is sized once, whatever the number of keys).  16 callers cost one warm-up and one copy of the key (round 3: one of
+// each per thread).  The table lock is held for the lookup only, never across HIP work; while a key is being built the other threads
+// serve it on the plain path.  Device memory is charged to one budget (REEF_MSM_KEY_CACHE_MB, default 16384 = 16 GiB of the
+// 288 GB); an allocation failure anywhere on this path empties the table and the thread's clones and retries once on the
+// plain, uncached path before the symbol gives up.
 struct SharedKey {
     int curve = 0, device = 0;
-    uint64_t h[2] = {0, 0};
+    uint64_t hs = 0;                   // hash of n and 64 sampled points: nominates on the fast path
+    uint64_t hf[2] = {0, 0};           // hash of every byte: identifies the entry on the slow path
     size_t n = 0;
     reef_msm_ctx *master = nullptr;    // owns the reference on the pre-shifted tables the clones share
-    void *raw = nullptr;               // device copy of the bytes the resident key was built from
-    size_t charged = 0;                // bytes charged to the process-wide budget
+    void *host_copy = nullptr;         // the bytes the resident key was built from: on the host (keys up to HOST_CMP_MAX_POINTS) ...
+    void *raw = nullptr;               // ... or on the device (larger keys)
+    size_t charged = 0;                // device bytes charged to the process-wide budget
     std::atomic<uint64_t> last_use{0};
     std::atomic<int> state{0};         // 0 nominated (seen, no copy), 1 being built, 2 resident, 3 evicted, 4 not worth another try
     uint32_t seen = 1;                 // under the table lock
     ~SharedKey();
 };
 std::atomic<size_t> g_cache_bytes{0};
-std::atomic<uint64_t> g_cache_builds{0}, g_cache_hits{0}, g_cache_clones{0};
+std::atomic<uint64_t> g_cache_builds{0}, g_cache_hits{0}, g_cache_clones{0}, g_cache_misspeculated{0};
 std::atomic<bool> g_process_exiting{false};   // destructors that run at process teardown must not touch HIP: it may be gone
 SharedKey::~SharedKey() {
+    free(host_copy);
     if (g_process_exiting.load()) return;          // the driver reclaims everything
     reef_msm_ctx_destroy(master);
     if (raw) reef_device_free(raw);
@@ -431,7 +440,7 @@ static size_t cache_budget() {
     }();
     return b;
 }
-constexpr size_t KEY_CACHE_MIN_POINTS = 1024, KEY_TABLE_ENTRIES = 16, LANES_PER_THREAD = 6;
+constexpr size_t KEY_CACHE_MIN_POINTS = 1024, KEY_TABLE_ENTRIES = 16, HOST_CMP_MAX_POINTS = (size_t)1 << 17;
 struct KeyTable {
     std::mutex mu;
     std::vector<std::shared_ptr<SharedKey>> keys;
@@ -447,112 +456,188 @@ static KeyTable &key_table() {
     static KeyTable *t = new KeyTable();            // never destroyed: static destructors run after HIP may be gone
     return *t;
 }
-struct Lane {                                      // one caller thread's handle on a resident key
-    std::shared_ptr<SharedKey> key;
-    reef_msm_ctx *clone = nullptr;
-};
+static inline uint64_t hmix(uint64_t x) {
+    x ^= x >> 30; x *= 0xbf58476d1ce4e5b9ull;
+    x ^= x >> 27; x *= 0x94d049bb133111ebull;
+    return x ^ (x >> 31);
+}
+static uint64_t sampled_hash(const reef_affine *p, size_t n) {
+    uint64_t h = hmix(n);
+    const size_t step = std::max<size_t>(1, n / 63);
+    auto take = [&](size_t i) {
+        const uint64_t *w = (const uint64_t *)(p + i);
+        for (int k = 0; k < 8; ++k) h = hmix(h ^ w[k]) + i;
+    };
+    for (size_t i = 0; i < n; i += step) take(i);
+    take(n - 1);
+    return h;
+}
+static void full_hash(const reef_affine *p, size_t n, uint64_t out[2]) {
+    const uint64_t *w = (const uint64_t *)p;
+    const size_t nw = n * 8;
+    uint64_t a[4] = {1, 2, 3, 4}, b[4] = {5, 6, 7, 8};   // four independent chains: the multiplies pipeline
+    for (size_t i = 0; i + 4 <= nw; i += 4)
+        for (int j = 0; j < 4; ++j) {
+            const uint64_t x = w[i + j];
+            a[j] = (a[j] ^ x) * 0x9e3779b97f4a7c15ull + (a[j] >> 29);
+            b[j] = (b[j] + x) * 0xc2b2ae3d27d4eb4full ^ (b[j] >> 31);
+        }
+    out[0] = hmix(a[0]) ^ hmix(a[1] + 1) ^ hmix(a[2] + 2) ^ hmix(a[3] + 3);
+    out[1] = hmix(b[0]) ^ hmix(b[1] + 1) ^ hmix(b[2] + 2) ^ hmix(b[3] + 3) ^ nw;
+}
 struct TlsCtx {
-    reef_msm_ctx *ctx[2] = {nullptr, nullptr};
-    int ctx_dev[2] = {-1, -1};
-    void *stage = nullptr;
+    reef_msm_ctx *ctx[2] = {nullptr, nullptr};      // plain path: re-keyed on every call
+    reef_msm_ctx *rctx[2] = {nullptr, nullptr};     // resident path: this thread's stream and workspace, attached to whichever shared key a call nominates
+    int ctx_dev[2] = {-1, -1}, rctx_dev[2] = {-1, -1};
+    reef_jacobian *pinned = nullptr;                // host-mapped: the speculative result lands here; word 24 is the verdict of a device compare
+    void *dev_flag = nullptr;
+    void *stage = nullptr;                          // device staging of the caller's bases (keys compared on the device)
     size_t stage_cap = 0;
     int stage_dev = -1;
-    std::vector<Lane> lanes;
-    void drop_lane(size_t i) {
-        reef_msm_ctx_destroy(lanes[i].clone);
-        lanes.erase(lanes.begin() + i);
-    }
-    void drop_lanes() {
-        while (!lanes.empty()) drop_lane(lanes.size() - 1);
+    void drop_resident() {
+        for (auto *&c : rctx) { reef_msm_ctx_destroy(c); c = nullptr; }
     }
     void drop_stage() {
         if (stage) reef_device_free(stage);
         stage = nullptr; stage_cap = 0; stage_dev = -1;
     }
     ~TlsCtx() {
-        if (g_process_exiting.load()) {            // process teardown: leak, never call into HIP
-            new std::vector<Lane>(std::move(lanes));
-            return;
-        }
+        if (g_process_exiting.load()) return;      // process teardown: never call into HIP
         for (auto *c : ctx) reef_msm_ctx_destroy(c);
-        drop_lanes();
+        drop_resident();
         drop_stage();
+        if (pinned) (void)hipHostFree(pinned);
+        if (dev_flag) reef_device_free(dev_flag);
     }
 };
 thread_local TlsCtx g_tls;
 
-static reef_status pippenger_plain(int curve, reef_jacobian *out, const reef_affine *points, size_t npoints, int points_loc, const reef_fe *scalars,
-                                   bool is_mont) {
+static reef_status pippenger_plain(int curve, reef_jacobian *out, const reef_affine *points, size_t npoints, const reef_fe *scalars, bool is_mont) {
     reef_msm_ctx *&c = g_tls.ctx[curve];
     int dev = 0;
     REEF_HIP_TRY(hipGetDevice(&dev));
     if (c && g_tls.ctx_dev[curve] != dev) { reef_msm_ctx_destroy(c); c = nullptr; }   // the caller moved to another GPU
     if (!c) {
-        REEF_TRY(reef_msm_ctx_create(&c, curve, points, npoints, points_loc, nullptr));
+        REEF_TRY(reef_msm_ctx_create(&c, curve, points, npoints, REEF_HOST, nullptr));
         g_tls.ctx_dev[curve] = dev;
     } else {
-        REEF_TRY(vt(curve)->ctx_rekey(c->impl, points, npoints, points_loc));
+        REEF_TRY(vt(curve)->ctx_rekey(c->impl, points, npoints, REEF_HOST));
     }
     return reef_msm(c, scalars, npoints, REEF_HOST, is_mont, out, REEF_HOST);
 }
 
-// The resident copy of a key whose second appearance this thread brought: raw bytes + pre-shifted tables.  Failure is never
-// fatal -- the key keeps being served on the plain path.
-static void build_resident(const std::shared_ptr<SharedKey> &k, const reef_affine *staged) {
+// The resident copy of a key whose second appearance this thread brought: the bytes + the pre-shifted tables.  Failure is
+// never fatal -- the key keeps being served on the plain path.
+static void build_resident(const std::shared_ptr<SharedKey> &k, const reef_affine *points) {
     const size_t bytes = k->n * sizeof(reef_affine);
+    const bool on_host = k->n <= HOST_CMP_MAX_POINTS;
     uint32_t T = 1;
     (void)reef_msm_plan_for(k->n, 0, 1, nullptr, nullptr, nullptr, &T);
-    const size_t cost = bytes * ((size_t)T + 1);       // T pre-shifted tables + the raw copy
+    const size_t cost = bytes * ((size_t)T + (on_host ? 0 : 1));   // T pre-shifted tables (+ the raw copy of a large key)
     int done = 4;
     if (g_cache_bytes.load() + cost <= cache_budget()) {
         reef_msm_opts o = {};
         o.bucket_groups = 1;
         o.byte_tables = 2;                             // never for a key the caller did not create: 256 KiB per point would dwarf the budget
         o.device = k->device;
-        void *raw = reef_device_alloc(bytes);
+        void *copy = on_host ? malloc(bytes) : reef_device_alloc(bytes);
         reef_msm_ctx *master = nullptr;
-        if (raw && reef_memcpy(raw, staged, bytes, REEF_DEVICE, REEF_DEVICE) == REEF_OK &&
-            reef_msm_ctx_create(&master, k->curve, staged, k->n, REEF_DEVICE, &o) == REEF_OK) {
-            k->raw = raw;
+        bool ok = copy != nullptr;
+        if (ok && on_host) memcpy(copy, points, bytes);
+        else if (ok) ok = reef_memcpy(copy, points, bytes, REEF_DEVICE, REEF_HOST) == REEF_OK;
+        ok = ok && reef_msm_ctx_create(&master, k->curve, points, k->n, REEF_HOST, &o) == REEF_OK;
+        if (ok) {
+            (on_host ? k->host_copy : k->raw) = copy;
             k->master = master;
             k->charged = cost;
             g_cache_bytes += cost;
             g_cache_builds += 1;
             done = 2;
-        } else if (raw) {
-            reef_device_free(raw);
+        } else if (copy) {
+            if (on_host) free(copy);
+            else reef_device_free(copy);
         }
     }
     int expect = 1;                                    // an entry evicted meanwhile (state 3) stays evicted
     k->state.compare_exchange_strong(expect, done, std::memory_order_release);
 }
 
-static reef_status pippenger_cached(int curve, reef_jacobian *out, const reef_affine *points, size_t npoints, const reef_fe *scalars, bool is_mont) {
+// The call on the resident key `k`, speculatively: *same = the caller's bytes are the key's (then *out holds the result).
+static reef_status pippenger_resident(const std::shared_ptr<SharedKey> &k, reef_jacobian *out, const reef_affine *points, size_t npoints,
+                                      const reef_fe *scalars, bool is_mont, bool *same) {
     const size_t bytes = npoints * sizeof(reef_affine);
+    const int curve = k->curve;
+    reef_msm_ctx *&c = g_tls.rctx[curve];
+    if (c && g_tls.rctx_dev[curve] != k->device) { reef_msm_ctx_destroy(c); c = nullptr; }
+    if (!c) {
+        REEF_TRY(reef_msm_ctx_clone(&c, k->master));
+        g_tls.rctx_dev[curve] = k->device;
+        g_cache_clones += 1;
+    } else {
+        REEF_TRY(reef_msm_ctx_attach(c, k->master));   // O(1): the thread's stream and workspace on another key's tables
+    }
+    if (!g_tls.pinned && hipHostMalloc((void **)&g_tls.pinned, 128, hipHostMallocDefault) != hipSuccess) {
+        (void)hipGetLastError();
+        g_tls.pinned = nullptr;
+        set_error("hipHostMalloc failed");
+        return REEF_ERR_OOM;
+    }
+    volatile uint32_t *verdict = reinterpret_cast<volatile uint32_t *>(g_tls.pinned + 1);
+    if (k->raw) {                                      // a large key: upload and compare on the thread's stream, ahead of the MSM
+        if (bytes > g_tls.stage_cap || g_tls.stage_dev != k->device) {
+            g_tls.drop_stage();
+            g_tls.stage = reef_device_alloc(bytes + bytes / 8);
+            if (!g_tls.stage) return REEF_ERR_OOM;
+            g_tls.stage_cap = bytes + bytes / 8;
+            g_tls.stage_dev = k->device;
+        }
+        if (!g_tls.dev_flag && !(g_tls.dev_flag = reef_device_alloc(16))) return REEF_ERR_OOM;
+        *verdict = 1;
+        REEF_TRY(vt(curve)->bytes_differ_async(reef_msm_ctx_stream(c), points, g_tls.stage, k->raw, bytes, g_tls.dev_flag, (void *)verdict));
+    }
+    REEF_TRY(reef_msm(c, scalars, npoints, REEF_HOST, is_mont, g_tls.pinned, REEF_DEVICE));   // enqueued; the result goes to host-mapped memory
+    bool eq = true;
+    if (k->host_copy) eq = memcmp(points, k->host_copy, bytes) == 0;                          // while the GPU works
+    REEF_TRY(reef_msm_ctx_sync(c));
+    if (k->raw) eq = *verdict == 0;
+    *same = eq;
+    if (eq) {
+        memcpy(out, g_tls.pinned, sizeof(reef_jacobian));
+        g_cache_hits += 1;
+    } else {
+        g_cache_misspeculated += 1;
+    }
+    return REEF_OK;
+}
+
+static reef_status pippenger_cached(int curve, reef_jacobian *out, const reef_affine *points, size_t npoints, const reef_fe *scalars, bool is_mont) {
     int dev = 0;
     REEF_HIP_TRY(hipGetDevice(&dev));
-    if (bytes > g_tls.stage_cap || g_tls.stage_dev != dev) {
-        g_tls.drop_stage();
-        g_tls.stage = reef_device_alloc(bytes + bytes / 8);
-        if (!g_tls.stage) return REEF_ERR_OOM;
-        g_tls.stage_cap = bytes + bytes / 8;
-        g_tls.stage_dev = dev;
-    }
-    REEF_TRY(reef_memcpy(g_tls.stage, points, bytes, REEF_DEVICE, REEF_HOST));
-    uint64_t h[2];
-    REEF_TRY(vt(curve)->fingerprint(g_tls.stage, bytes, h));
-    const reef_affine *staged = (const reef_affine *)g_tls.stage;
-    for (size_t i = g_tls.lanes.size(); i-- > 0;)      // clones of keys the table has let go: give their memory back
-        if (g_tls.lanes[i].key->state.load(std::memory_order_acquire) == 3) g_tls.drop_lane(i);
-
     KeyTable &tab = key_table();
+    const uint64_t hs = sampled_hash(points, npoints);
     std::shared_ptr<SharedKey> k;
+    {                                                  // fast path: the most recently used resident key the samples nominate
+        std::lock_guard<std::mutex> lk(tab.mu);
+        for (auto &e : tab.keys)
+            if (e->curve == curve && e->device == dev && e->n == npoints && e->hs == hs && e->state.load(std::memory_order_acquire) == 2 &&
+                (!k || e->last_use.load() > k->last_use.load()))
+                k = e;
+        if (k) k->last_use.store(++tab.tick);
+    }
+    if (k) {
+        bool same = false;
+        REEF_TRY(pippenger_resident(k, out, points, npoints, scalars, is_mont, &same));
+        if (same) return REEF_OK;
+        k.reset();                                     // another key with the same samples: the whole content decides
+    }
+    uint64_t hf[2];
+    full_hash(points, npoints, hf);
     bool builder = false;
     {
         std::lock_guard<std::mutex> lk(tab.mu);
         const uint64_t now = ++tab.tick;
         for (auto &e : tab.keys)
-            if (e->curve == curve && e->device == dev && e->n == npoints && e->h[0] == h[0] && e->h[1] == h[1]) k = e;
+            if (e->curve == curve && e->device == dev && e->n == npoints && e->hf[0] == hf[0] && e->hf[1] == hf[1]) k = e;
         if (k) {
             k->last_use.store(now);
             k->seen += 1;
@@ -574,40 +659,20 @@ static reef_status pippenger_cached(int curve, reef_jacobian *out, const reef_af
             }
             if (tab.keys.size() < KEY_TABLE_ENTRIES) {
                 auto e = std::make_shared<SharedKey>();
-                e->curve = curve; e->device = dev; e->n = npoints; e->h[0] = h[0]; e->h[1] = h[1];
+                e->curve = curve; e->device = dev; e->n = npoints; e->hs = hs; e->hf[0] = hf[0]; e->hf[1] = hf[1];
                 e->last_use.store(now);
                 tab.keys.push_back(e);
             }
         }
     }
-    if (k && !builder && k->state.load(std::memory_order_acquire) == 2) {
-        int same = 0;
-        REEF_TRY(vt(curve)->bytes_equal(g_tls.stage, k->raw, bytes, &same));
-        if (same) {
-            Lane *lane = nullptr;
-            for (auto &l : g_tls.lanes)
-                if (l.key == k) lane = &l;
-            if (!lane) {
-                if (g_tls.lanes.size() >= LANES_PER_THREAD) g_tls.drop_lane(0);      // oldest first
-                reef_msm_ctx *c = nullptr;
-                REEF_TRY(reef_msm_ctx_clone(&c, k->master));
-                g_cache_clones += 1;
-                g_tls.lanes.push_back(Lane{k, c});
-                lane = &g_tls.lanes.back();
-            } else if (lane != &g_tls.lanes.back()) {  // keep the lanes in order of use
-                Lane l = *lane;
-                g_tls.lanes.erase(g_tls.lanes.begin() + (lane - &g_tls.lanes[0]));
-                g_tls.lanes.push_back(l);
-                lane = &g_tls.lanes.back();
-            }
-            g_cache_hits += 1;
-            return reef_msm(lane->clone, scalars, npoints, REEF_HOST, is_mont, out, REEF_HOST);
-        }
-        // a fingerprint collision: this is another key, serve it uncached
+    if (k && !builder && k->state.load(std::memory_order_acquire) == 2) {   // resident, but not what the samples nominated first
+        bool same = false;
+        REEF_TRY(pippenger_resident(k, out, points, npoints, scalars, is_mont, &same));
+        if (same) return REEF_OK;
     }
-    const reef_status st = pippenger_plain(curve, out, staged, npoints, REEF_DEVICE, scalars, is_mont);
+    const reef_status st = pippenger_plain(curve, out, points, npoints, scalars, is_mont);
     if (builder) {
-        if (st == REEF_OK) build_resident(k, staged);
+        if (st == REEF_OK) build_resident(k, points);
         else { int expect = 1; k->state.compare_exchange_strong(expect, 0); }
     }
     return st;
@@ -617,13 +682,13 @@ static reef_status pippenger_try(int curve, reef_jacobian *out, const reef_affin
     static const bool cache_on = !(getenv("REEF_MSM_KEY_CACHE") && atoi(getenv("REEF_MSM_KEY_CACHE")) == 0);
     static std::once_flag exit_hook;
     std::call_once(exit_hook, [] { atexit([] { g_process_exiting.store(true); }); });
-    reef_status st = (!cache_on || npoints < KEY_CACHE_MIN_POINTS) ? pippenger_plain(curve, out, points, npoints, REEF_HOST, scalars, is_mont)
+    reef_status st = (!cache_on || npoints < KEY_CACHE_MIN_POINTS) ? pippenger_plain(curve, out, points, npoints, scalars, is_mont)
                                                                      : pippenger_cached(curve, out, points, npoints, scalars, is_mont);
     if (st == REEF_ERR_OOM) {                           // give the cache's memory back and serve the call uncached
         key_table().clear();
-        g_tls.drop_lanes();
+        g_tls.drop_resident();
         g_tls.drop_stage();
-        st = pippenger_plain(curve, out, points, npoints, REEF_HOST, scalars, is_mont);
+        st = pippenger_plain(curve, out, points, npoints, scalars, is_mont);
     }
     return st;
 }
@@ -647,6 +712,8 @@ void reef_key_cache_info(reef_key_cache_stats *out) {
     out->builds = g_cache_builds.load();
     out->hits = g_cache_hits.load();
     out->clones = g_cache_clones.load();
+    out->misspeculated = g_cache_misspeculated.load();
+    out->reserved = 0;
 }
 void reef_key_cache_clear(void) { key_table().clear(); }
 

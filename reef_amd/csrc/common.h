@@ -55,6 +55,7 @@ struct CurveVTable {
     reef_status (*ctx_create)(void **impl, const reef_affine *bases, size_t n, int loc, const reef_msm_opts *opts);
     reef_status (*ctx_rekey)(void *impl, const reef_affine *bases, size_t n, int loc);
     reef_status (*ctx_clone)(void **impl, void *src);
+    reef_status (*ctx_attach)(void *impl, void *src_impl);
     void (*ctx_destroy)(void *impl);
     reef_status (*ctx_sync)(void *impl);
     void *(*ctx_stream)(void *impl);
@@ -102,8 +103,9 @@ struct CurveVTable {
     // row N1: commitment-key derivation (hash to the curve; coordinates in the curve's base field)
     reef_status (*derive_generators)(const uint8_t *label, size_t label_len, size_t n, const reef_keygen_params *kp, bool is_mont, reef_affine *out,
                                      int out_loc);
-    reef_status (*fingerprint)(const void *dev, size_t bytes, uint64_t out[2]);
-    reef_status (*bytes_equal)(const void *dev_a, const void *dev_b, size_t bytes, int *equal);
+    // on `stream`: host_src -> dev_stage, then *pinned_verdict = (dev_stage differs from dev_ref) ? 1 : 0 (asynchronous)
+    reef_status (*bytes_differ_async)(void *stream, const void *host_src, void *dev_stage, const void *dev_ref, size_t bytes, void *dev_flag,
+                                      void *pinned_verdict);
     reef_status (*plan_for)(size_t n, uint32_t c_opt, uint32_t g_opt, uint32_t *c, uint32_t *w, uint32_t *g, uint32_t *t);
 };
 

@@ -119,6 +119,11 @@ class MsmContext:
         check(self._lib.reef_msm_ctx_clone(ctypes.byref(h), self._h))
         return MsmContext(self.curve, None, self.n, _handle=h)
 
+    def attach(self, other: "MsmContext") -> None:
+        """This handle moves to `other`'s resident key (as a clone of it would be), keeping its stream and workspace."""
+        check(self._lib.reef_msm_ctx_attach(self._h, other._h))
+        self.n = other.n
+
     def close(self) -> None:
         if getattr(self, "_h", None):
             self._lib.reef_msm_ctx_destroy(self._h)

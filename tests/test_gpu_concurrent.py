@@ -69,8 +69,9 @@ def test_eight_threads_share_one_key(gpu_lib, cref, cases):
     assert after["builds"] - before["builds"] == cached_keys, (before, after)       # one build per key, not one per thread
     assert after["resident_keys"] == cached_keys
     assert after["hits"] - before["hits"] >= cached_keys * 2 * 8 * 4, (before, after)   # at least every call of generations 1 and 2
-    per_key = {n: 64 * n * (msm.plan_for(n, bucket_groups=1)["tables"] + 1) for n in SIZES if n >= 1024}
+    per_key = {n: 64 * n * msm.plan_for(n, bucket_groups=1)["tables"] for n in SIZES if n >= 1024}    # the bytes for the comparison stay on the host up to 2^17 points
     assert after["resident_bytes"] == 2 * sum(per_key.values())                     # one copy of each key, 16 callers or not
+    assert after["misspeculated"] == before["misspeculated"]
 
 
 def test_threads_on_different_keys_and_curves_at_once(gpu_lib, cref, cases):
@@ -86,6 +87,54 @@ def test_threads_on_different_keys_and_curves_at_once(gpu_lib, cref, cases):
                 j = (t + step) % 4
                 assert msm.compress(cid, msm.mult_pippenger(cid, bases, scal[j])) == want[j], (generation, t, cid, n)
         run_threads(8, work)
+
+
+@pytest.mark.parametrize("n", [5000, (1 << 17) + 1000])
+def test_keys_that_differ_in_one_unsampled_point(n, gpu_lib, cref):
+    """The fast nomination looks at 64 sampled points; two keys that agree on all of them (one point edited in place) are told
+    apart by the comparison of every byte that runs beside the speculative MSM -- on the host for keys up to 2^17 points, on the
+    device above -- and each call returns the commitment of the key it was given, from several threads alternating between them."""
+    from reef_amd import msm
+    cid = 1
+    a = cref.gen_bases_ap(cid, 31337, 3, n)
+    b = a.copy()
+    b[n // 2 + 1] = cref.gen_bases_ap(cid, 99, 1, 1)[0]       # not one of the sampled indices (multiples of n // 63, and n - 1)
+    assert (n // 2 + 1) % max(1, n // 63) != 0
+    sc = cref.gen_scalars(cid, 5, n)
+    want = {0: cref.compress(cid, cref.msm_pippenger(cid, a, sc, threads=8)), 1: cref.compress(cid, cref.msm_pippenger(cid, b, sc, threads=8))}
+    assert want[0] != want[1]
+    before = cache_info()
+
+    def work(t):
+        for rep in range(8):
+            which = (t + rep) % 2
+            assert msm.compress(cid, msm.mult_pippenger(cid, (a, b)[which], sc)) == want[which], (t, rep)
+    run_threads(4, work)
+    after = cache_info()
+    assert after["builds"] - before["builds"] == 2 and after["misspeculated"] > before["misspeculated"]
+
+
+def test_attach_moves_a_handle_between_keys(gpu_lib, cref):
+    """reef_msm_ctx_attach: one stream and workspace serving several resident keys in turn (what the drop-in symbols do per thread)."""
+    from reef_amd import msm
+    cid = 0
+    keys = [cref.gen_bases_ap(cid, 600 + 7 * j, 3, n) for j, n in enumerate((700, 5000, 40000))]      # nibble tables, c = 13 plans
+    scs = [cref.gen_scalars(cid, 60 + j, len(kb)) for j, kb in enumerate(keys)]
+    want = [cref.compress(cid, cref.msm_pippenger(cid, kb, sc, threads=4)) for kb, sc in zip(keys, scs)]
+    owners = [msm.MsmContext(cid, kb, bucket_groups=1) for kb in keys]
+    h = owners[0].clone()
+    for rnd in range(3):
+        for j in (2, 0, 1, 1, 2):
+            h.attach(owners[j])
+            assert msm.compress(cid, h.msm(scs[j])) == want[j], (rnd, j)
+    owners[2].close()                                 # the handle keeps the key it is attached to alive
+    assert msm.compress(cid, h.msm(scs[2])) == want[2]
+    with pytest.raises(msm.ReefError):
+        other = msm.MsmContext(1, cref.gen_bases_ap(1, 1, 1, 8))
+        h.attach(other)                               # another curve
+    h.close()
+    for o in owners[:2]:
+        o.close()
 
 
 def test_table_turnover_under_concurrency(gpu_lib, cref):
