@@ -212,7 +212,8 @@ def hbm_bound_leg(ell=26):
 
 def _diag(tag):
     """REEF_BENCH_DIAG=1: how the final SNARK's three arguments share the GPU at this point of the process (stderr)."""
-    if os.environ.get("REEF_BENCH_DIAG") != "1":
+    at = os.environ.get("REEF_BENCH_DIAG_AT")          # one probe at the named point only (the first replay of the process)
+    if not (os.environ.get("REEF_BENCH_DIAG") == "1" or (at and at == tag)):
         return
     from reef_amd import replay
     g = replay.run("cfg3", nofold=True, tables=False)

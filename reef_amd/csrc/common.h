@@ -1,6 +1,10 @@
 // Host-side plumbing shared by the per-curve engines and the C ABI (not part of the ABI).
 #pragma once
+#include <algorithm>
 #include <atomic>
+#include <mutex>
+#include <stdlib.h>
+#include <vector>
 #include <hip/hip_runtime.h>
 #include <stddef.h>
 #include <stdint.h>
@@ -48,6 +52,104 @@ struct DevBuf {
         cap = 0;
     }
     template <class T> T *as() const { return reinterpret_cast<T *>(p); }
+};
+
+// ---- the library's HIP streams: one small process-wide pool ------------------------------------------------------------
+// The HIP runtime maps a process's streams onto GPU_MAX_HW_QUEUES hardware queues by COUNT: a new stream goes to the queue with
+// the fewest streams, whether those are busy or idle, and keeps it for life; streams on one queue run in turn.  A stream per
+// context therefore lets idle contexts push the busy ones of a long-lived process onto shared queues -- measured in round 4:
+// the final SNARK's three arguments, issued from three threads at once, took 9.6 ms inside bench.py's process where the bare
+// harness takes 6.1 ms, and 6.2 ms in the same process once an earlier replay had shifted the runtime's counts
+// (tools/diag_queues2.py, profiles/r04_concurrency_bisect.txt).  So contexts do not own streams any more: the library keeps at
+// most REEF_MSM_STREAMS (default 8) streams per device, created one at a time when every existing one has a caller at work, and
+// a context (or a stateless call) takes the stream with the fewest callers AT WORK each time it starts from idle -- all its
+// earlier work has been waited for -- and keeps it until it is idle again.  Sharing a stream only adds ordering, never removes it.
+struct PoolStream {
+    hipStream_t s = nullptr;
+    int device = 0;
+    std::atomic<int> active{0};      // callers between their first enqueue and the wait that found them idle again
+};
+struct StreamPool {
+    std::mutex mu;
+    std::vector<PoolStream *> streams;               // entries are never moved or destroyed: the pointers handed out stay valid
+    static size_t limit() {
+        static const size_t v = [] { const char *e = getenv("REEF_MSM_STREAMS"); const long n = e ? atol(e) : 8; return (size_t)(n < 1 ? 1 : n > 64 ? 64 : n); }();
+        return v;
+    }
+    // the stream of `device` with the fewest callers at work (counted for the caller from here on: leave() when idle again)
+    reef_status pick(int device, PoolStream **out) {
+        std::lock_guard<std::mutex> lk(mu);
+        PoolStream *best = nullptr;
+        size_t on_device = 0;
+        for (PoolStream *p : streams)
+            if (p->device == device) {
+                ++on_device;
+                if (!best || p->active.load(std::memory_order_relaxed) < best->active.load(std::memory_order_relaxed)) best = p;
+            }
+        if (!best || (best->active.load(std::memory_order_relaxed) > 0 && on_device < limit())) {
+            PoolStream *p = new PoolStream();
+            p->device = device;
+            hipError_t e = hipStreamCreateWithFlags(&p->s, hipStreamNonBlocking);   // the caller's current device is `device` (DeviceGuard)
+            if (e != hipSuccess) {
+                delete p;
+                if (!best) { set_error("hipStreamCreate: %s", hipGetErrorString(e)); return REEF_ERR_HIP; }
+                (void)hipGetLastError();
+            } else {
+                streams.push_back(p);
+                best = p;
+            }
+        }
+        best->active.fetch_add(1, std::memory_order_relaxed);
+        *out = best;
+        return REEF_OK;
+    }
+    static void leave(PoolStream *p) {
+        if (p) p->active.fetch_sub(1, std::memory_order_relaxed);
+    }
+    // Creating a stream is expensive while the runtime still has hardware queues to create (several ms each, measured: the first
+    // concurrent use of three contexts read 23 ms instead of 6), so it is done where contexts are CREATED, never in a hot call if
+    // it can be helped: a new context makes sure the pool holds as many streams as there are contexts alive (up to the limit).
+    std::atomic<int> contexts_alive{0};
+    reef_status context_created(int device) {
+        const size_t want = std::min<size_t>((size_t)std::max(1, ++contexts_alive), limit());
+        std::lock_guard<std::mutex> lk(mu);
+        size_t on_device = 0;
+        for (PoolStream *p : streams) on_device += p->device == device;
+        for (; on_device < want; ++on_device) {
+            PoolStream *p = new PoolStream();
+            p->device = device;
+            hipError_t e = hipStreamCreateWithFlags(&p->s, hipStreamNonBlocking);
+            if (e != hipSuccess) { delete p; set_error("hipStreamCreate: %s", hipGetErrorString(e)); return REEF_ERR_HIP; }
+            streams.push_back(p);
+        }
+        return REEF_OK;
+    }
+    void context_destroyed() { --contexts_alive; }
+};
+inline StreamPool &stream_pool() {
+    static StreamPool *p = new StreamPool();            // never destroyed: static destructors run after HIP may be gone
+    return *p;
+}
+// What a context (MSM or sum-check) holds of the pool.  Protocol, under the context's own lock: enter() before the first enqueue
+// of a call, then idle() once the stream has been waited for (hipStreamSynchronize) -- a call that returns with work in flight
+// simply does not call it and the context stays on its stream.  pin(): the stream was handed to the caller (reef_msm_ctx_stream,
+// to order RCCL / torch work after it) and must not change any more.
+struct StreamLease {
+    PoolStream *ps = nullptr;
+    bool counted = false, pinned = false;
+    reef_status enter(int device, hipStream_t *stream) {
+        if (!counted) {
+            if (pinned && ps) ps->active.fetch_add(1, std::memory_order_relaxed);
+            else REEF_TRY(stream_pool().pick(device, &ps));
+            counted = true;
+        }
+        *stream = ps->s;
+        return REEF_OK;
+    }
+    void idle() {
+        if (counted) StreamPool::leave(ps);
+        counted = false;
+    }
 };
 
 // Per-curve entry points, implemented once per curve in kernels_<curve>.hip via engine.inc.
