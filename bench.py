@@ -164,9 +164,9 @@ def hbm_bound_leg(ell=26):
     (r1cs.rs:2320-2376: gen_eq_table, then the rounds).  Since round 3 the EQ table is never written out while the rounds fold its
     high index bits (it stays two factor tables plus point masses), so the pass streams T only; the dense form (both tables
     streamed, rounds 1-2) is timed beside it on a caller-given EQ.  Check: the sum-check identity of the round."""
-    from oracle.sumcheck_oracle import Q
     from reef_amd import msm
     from reef_amd.sumcheck import SumCheck
+    Q = msm.PALLAS_SCALAR_Q
     n = 1 << ell
     doc = msm.gen_scalars("pallas", 0xD0C, n, kind=0, mont=False, device=True)   # full-width entries: no row of the table is constant or small,
     eqv = msm.gen_scalars("pallas", 0xE9, n, kind=0, mont=False, device=True)   # so round one streams 32-byte entries like every later round
@@ -220,43 +220,53 @@ def _diag(tag):
     print(f"[diag] {tag}: three arguments at once {g['three_arguments_concurrently_ms']} ms", file=sys.stderr, flush=True)
 
 
-def replay_leg():
-    """After the timed region, never `value`: the MSM sequence of one `reef --prove` on BASELINE.json configs[2]
+SAFA_CAVEAT = ("MSM lengths are PREDICTIONS of Reef's cost model (src/backend/costs.rs restated) for ASSUMED SAFA shapes -- cfg3: the 12-state "
+               "automaton of '.*password.*'; cfg4: a made-up 'DNA motif' of ~128 transitions / 130 states -- not measurements of a Reef run "
+               "(tests/golden/replay_shapes.json `inputs`, `note`)")
+
+
+def replay_leg(cfg="cfg3", with_tables=True):
+    """After the timed region, never `value`: the MSM sequence of one `reef --prove` on BASELINE.json configs[2] (cfg3, the 1 MiB
+    document) or configs[3] (cfg4: north_star's own target, the 16 MiB DNA document with --hybrid -b 32)
     (src/backend/framework.rs:664-723) issued in-process through the C ABI by the C++ harness (per-step scalars in host
     memory, commitments back to the host, every one checked).  Runs BEFORE the CPU baseline: the sequence is bound by
     host latency, and a container that has just burnt its CPU quota on the oracle's threads is throttled."""
     from reef_amd import replay
     out = {}
-    g = replay.run("cfg3", nofold=True, tables=False)
+    g = replay.run(cfg, nofold=True, tables=False)
     out.update({"workload": g["replay"], "shapes": "tests/golden/replay_shapes.json (Reef's cost model restated: oracle/costs_oracle.py)",
+                "shapes_caveat": SAFA_CAVEAT,
                 "w1": g["w1"], "c1": g["c1"], "w2": g["w2"], "c2": g["c2"], "steps": g["steps"],
                 "fold_ms_per_step": g["ms_per_step"], "fold_ms_per_step_batched_pairs": g["ms_per_step_batched_pairs"],
+                "fold_ms_per_step_concurrent": g.get("ms_per_step_concurrent"),
                 "ipa_ms": g["ipa_pallas_ms"] + g["ipa_vesta_ms"], "consistency_ipa_ms": g["consistency_ipa_ms"],
                 "three_arguments_concurrently_ms": g.get("three_arguments_concurrently_ms"),
-                "three_arguments_note": "the two Spartan arguments and the consistency argument from three caller threads at once; in THIS process, after the "
-                                        "bench's own multi-GiB allocations, it reads 9-10 ms -- the harness alone (or this leg after an early replay in the same "
-                                        "process: REEF_BENCH_DIAG=1) reads 6.1 ms against 12.7 ms one after the other (profiles/r03_concurrent_ipa.txt)",
+                "three_arguments_note": "the two Spartan arguments and the consistency argument from three caller threads at once (one after the other: ipa_ms + "
+                                        "consistency_ipa_ms); since round 4 the library's contexts share one pool of streams by activity, so the figure no longer "
+                                        "depends on what else the process has alive (profiles/r04_concurrency_bisect.txt: 9.6 -> 6.0 ms in this process)",
+                "sumcheck_ms_per_step": g.get("sumcheck_ms_per_step"), "sumcheck_table_log": g.get("sumcheck_table_log"),
                 "total_prove_msm_ms": g["total_prove_msm_ms"], "total_prove_gpu_ms": g["total_prove_gpu_ms"], "setup_ms": g["setup_ms"],
                 "commitments_checked_against_dlog": g["commitments_checked_against_dlog"],
                 "scalars": "host memory in, commitments back to the host (PCIe-inclusive)", "ipa": g["ipa"]})
-    try:
-        t = replay.run("cfg3", nofold=True, tables=True)
-        out["byte_tables"] = {"fold_ms_per_step": t["ms_per_step"], "ipa_ms": t["ipa_pallas_ms"] + t["ipa_vesta_ms"],
-                              "three_arguments_concurrently_ms": t.get("three_arguments_concurrently_ms"),
-                              "total_prove_msm_ms": t["total_prove_msm_ms"], "setup_ms": t["setup_ms"],
-                              "commitments_checked_against_dlog": t["commitments_checked_against_dlog"]}
-    except Exception as e:
-        out["byte_tables"] = {"error": str(e)}
+    if with_tables:
+        try:
+            t = replay.run(cfg, nofold=True, tables=True)
+            out["byte_tables"] = {"fold_ms_per_step": t["ms_per_step"], "ipa_ms": t["ipa_pallas_ms"] + t["ipa_vesta_ms"],
+                                  "three_arguments_concurrently_ms": t.get("three_arguments_concurrently_ms"),
+                                  "total_prove_msm_ms": t["total_prove_msm_ms"], "setup_ms": t["setup_ms"],
+                                  "commitments_checked_against_dlog": t["commitments_checked_against_dlog"]}
+        except Exception as e:
+            out["byte_tables"] = {"error": str(e)}
     return out
 
 
-def replay_cpu_leg(out, cpu_threads=None):
+def replay_cpu_leg(out, cfg="cfg3", cpu_threads=None):
     """The same sequence on the host cores through the oracle (test infrastructure used as the reported CPU side)."""
     from reef_amd import replay
     from oracle import replay_cpu
-    c = replay_cpu.run("cfg3", replay.SHAPES_PATH, cpu_threads or os.cpu_count() or 1)
+    c = replay_cpu.run(cfg, replay.SHAPES_PATH, cpu_threads or os.cpu_count() or 1)
     out.update({"cpu_restatement_ms": c["total_prove_msm_ms"], "cpu_fold_ms_per_step": c["ms_per_step"],
-                "cpu_ipa_ms": c["ipa_pallas_ms"] + c["ipa_vesta_ms"], "cores": c["threads"], "cpu_kind": c["kind"]})
+                "cpu_ipa_ms": c["ipa_pallas_ms"] + c["ipa_vesta_ms"], "cpu_consistency_ipa_ms": c["consistency_ipa_ms"], "cores": c["threads"], "cpu_kind": c["kind"]})
 
 
 def main():
@@ -611,19 +621,25 @@ def main():
     if rank == 0:
         # HBM traffic of the dominant kernel: PMC counters need their own rocprofv3 passes (never
         # combined with timing), so the value is read from the committed profile of this command
+        # a profile is taken only if it was collected on the kernels this run executes (sources fingerprint) and on this plan; a stale
+        # one is refused rather than quoted (no fall-back to an older round's file)
         traffic, traffic_src = None, None
-        for prof_name in ("r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
-            try:
-                prof = json.load(open(os.path.join(ROOT, "profiles", prof_name)))
-                pc = prof["config"]
-                if (pc["curve"], pc["logn"], pc["window_bits"], pc["bucket_groups"]) == (a.curve, a.logn, plan["window_bits"], plan["bucket_groups"]):
-                    # the kernel's template arguments changed between rounds (r03 added the fused-merge flag)
-                    accum = [v for k, v in prof["kernels"].items() if k.startswith(f"k_accum0<{msm.curve_id(a.curve)}")]
-                    traffic = max(v["hbm_bytes_per_launch"] for v in accum)
-                    traffic_src = f"profiles/{prof_name} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes)"
-                    break
-            except (OSError, KeyError, ValueError):
-                pass
+        from reef_amd import _ffi as _f
+        prof_name = "r04_pmc_traffic.json"
+        try:
+            prof = json.load(open(os.path.join(ROOT, "profiles", prof_name)))
+            pc = prof["config"]
+            same_plan = (pc["curve"], pc["logn"], pc["window_bits"], pc["bucket_groups"]) == (a.curve, a.logn, plan["window_bits"], plan["bucket_groups"])
+            if prof.get("kernel_sources_sha16") != _f.kernel_sources_sha16():
+                traffic_src = f"REFUSED: profiles/{prof_name} was collected on other kernel sources ({prof.get('kernel_sources_sha16')} != {_f.kernel_sources_sha16()}); re-run tools/pmc_traffic.py"
+            elif not same_plan:
+                traffic_src = f"REFUSED: profiles/{prof_name} describes another plan ({pc})"
+            else:
+                accum = [v for k, v in prof["kernels"].items() if k.startswith(f"k_accum0<{msm.curve_id(a.curve)}")]
+                traffic = max(v["hbm_bytes_per_launch"] for v in accum)
+                traffic_src = f"profiles/{prof_name} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes on kernel sources {prof['kernel_sources_sha16']})"
+        except (OSError, KeyError, ValueError) as e:
+            traffic_src = f"no usable profiles/{prof_name}: {e}"
         pairs = n * B * MPS * (1 if by_windows else a.gpus) * a.steps
         value = pairs / elapsed
         achieved = BYTES_PER_PAIR * n * B / (acc_ms * 1e-3) / 1e9 if acc_ms > 0 else None
@@ -675,17 +691,19 @@ def main():
             except Exception as e:
                 out["roofline"]["hbm_bound_row"] = {"error": str(e)}
             _diag("after the HBM-bound leg")
-            try:
-                out["config"]["replay_cfg3"] = replay_leg()
-            except Exception as e:         # a side measurement never takes the bench line down
-                out["config"]["replay_cfg3"] = {"error": str(e)}
+            for cfg_ in ("cfg3", "cfg4"):  # BASELINE configs[2] and configs[3] (north_star's own target document: 16 MiB)
+                try:
+                    out["config"]["replay_" + cfg_] = replay_leg(cfg_, with_tables=cfg_ == "cfg3")
+                except Exception as e:     # a side measurement never takes the bench line down
+                    out["config"]["replay_" + cfg_] = {"error": str(e)}
         if a.gpus == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(msm.curve_id(a.curve), a.cpu_seconds)
-            if side_legs and "error" not in out["config"]["replay_cfg3"]:
-                try:
-                    replay_cpu_leg(out["config"]["replay_cfg3"], cpu_threads=out["cpu_baseline"].get("cores"))
-                except Exception as e:
-                    out["config"]["replay_cfg3"]["cpu_error"] = str(e)
+            for cfg_ in ("cfg3", "cfg4"):
+                if side_legs and "error" not in out["config"]["replay_" + cfg_]:
+                    try:
+                        replay_cpu_leg(out["config"]["replay_" + cfg_], cfg_, cpu_threads=out["cpu_baseline"].get("cores"))
+                    except Exception as e:
+                        out["config"]["replay_" + cfg_]["cpu_error"] = str(e)
         os.write(json_fd, (json.dumps(out) + "\n").encode())
     if multi:
         dist.barrier()

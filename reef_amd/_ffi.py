@@ -148,6 +148,17 @@ def check(status: int) -> None:
         raise ReefError(status, load().reef_last_error().decode(errors="replace"))
 
 
+def kernel_sources_sha16() -> str:
+    """Fingerprint of the sources the MSM kernels are compiled from: a PMC profile in profiles/ describes THESE kernels or it is
+    stale (bench.py refuses a stale one for roofline.traffic; tools/pmc_traffic.py records the fingerprint it ran on)."""
+    import hashlib
+    h = hashlib.sha256()
+    for name in ("msm_kernels.inc", "engine.inc", "field.h", "ec.h", "ec_coop.h", "field_mad_gfx950.h", "Makefile"):
+        with open(os.path.join(CSRC, name), "rb") as f:
+            h.update(name.encode() + b"\0" + f.read())
+    return h.hexdigest()[:16]
+
+
 def declared_symbols() -> list[str]:
     """Function names declared in include/reef_msm.h (used by the ABI export test)."""
     import re

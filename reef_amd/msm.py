@@ -17,6 +17,11 @@ from . import _ffi
 from ._ffi import PALLAS, REEF_DEVICE, REEF_HOST, VESTA, MsmOpts, ReefError, check  # noqa: F401
 
 CURVE_IDS = {"pallas": PALLAS, "vesta": VESTA, PALLAS: PALLAS, VESTA: VESTA}
+# The two Pasta primes (the same constants as csrc/field_consts.h): Pallas is y^2 = x^3 + 5 over F_p with q points, Vesta the
+# same equation over F_q with p points.  Reef's CirC modulus is q (src/backend/r1cs_helper.rs:37-38).
+PALLAS_BASE_P = 0x40000000000000000000000000000000224698fc094cf91b992d30ed00000001
+PALLAS_SCALAR_Q = 0x40000000000000000000000000000000224698fc0994a8dd8c46eb2100000001
+SCALAR_MODULUS = {PALLAS: PALLAS_SCALAR_Q, VESTA: PALLAS_BASE_P}
 Buf = Union[np.ndarray, "DeviceBuffer", int]
 
 

@@ -1,6 +1,6 @@
 #!/bin/bash
 # On the MI355X box: everything profiles/ holds for a round.  usage: tools/collect_profiles.sh OUTDIR [rNN]
-out=$(realpath -m $1); R=${2:-r03}; export REEF_ROUND=$R
+out=$(realpath -m $1); R=${2:-r04}; export REEF_ROUND=$R
 mkdir -p $out; export TMPDIR=/tmp; root=$GRAFT_REPO_ROOT
 python $root/bench.py > $out/${R}_bench.json 2> $out/${R}_bench.err
 # per-kernel time of the same timed region: the legs that run other sizes through the same kernels after it (replay, CPU) are left out

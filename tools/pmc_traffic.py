@@ -23,7 +23,8 @@ import sys
 from collections import defaultdict
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-RND = os.environ.get("REEF_ROUND", "r02")      # file prefix: profiles are named per round
+sys.path.insert(0, ROOT)
+RND = os.environ.get("REEF_ROUND", "r04")      # file prefix: profiles are named per round
 outdir = os.path.abspath(sys.argv[1])
 bench_args = sys.argv[2:] or ["--steps", "4", "--warmup", "1", "--msms-per-step", "1", "--no-cpu-baseline", "--no-replay", "--streams", "1"]
 os.makedirs(outdir, exist_ok=True)
@@ -77,6 +78,7 @@ json.dump({
                 "stream of 32768 KiB reports 16415 (factor 2.0, the gfx950 half-count of MI355X_MICROARCH.md); WRITE_SIZE of k_recode "
                 "reports 65536 KiB for 65536 KiB written (factor 1.0).",
     "command": "python tools/pmc_traffic.py <out> " + " ".join(bench_args),
+    "kernel_sources_sha16": __import__("reef_amd._ffi", fromlist=["x"]).kernel_sources_sha16(),
     "config": {"curve": "pallas", "logn": cfg["points_per_gpu"].bit_length() - 1, "window_bits": cfg["window_bits"],
                "bucket_groups": cfg["bucket_groups"]},
     "kernels": kernels,
