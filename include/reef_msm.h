@@ -21,7 +21,7 @@
  * (it owns one HIP stream and one workspace); use one ctx (or clone) per concurrent caller.
  *
  * ABI changelog (reef_abi_version()):
- *   4  round 4: reef_runtime_init / reef_abi_version / reef_msm_ctx_attach / reef_key_cache_info added; the drop-in symbols' key cache is one table per process
+ *   4  round 4: reef_runtime_init / reef_abi_version / reef_msm_ctx_attach / reef_msm_multi / reef_key_cache_info added; the drop-in symbols' key cache is one table per process
  *      (clones per calling thread) instead of one cache per thread.
  *   3  round 3: reef_msm_opts.byte_tables = 0 changed meaning from "build the byte tables in the background" to "follow the
  *      process-wide policy: none unless REEF_MSM_WIDE=1" -- callers that pass zeroed opts no longer get the byte-table path
@@ -139,6 +139,17 @@ void *reef_msm_ctx_stream(reef_msm_ctx *ctx);
  * With out_loc == REEF_DEVICE the call only enqueues work (no host sync). */
 reef_status reef_msm(reef_msm_ctx *ctx, const reef_fe *scalars, size_t n, int scalars_loc,
                      bool is_mont, reef_jacobian *out, int out_loc);
+
+/* `count` independent MSMs issued at once, MSM i on ctxs[i] with scalars[i][0 .. n[i]): all are enqueued before any is waited
+ * for, each on the stream its context takes from the library's pool, so their latency-bound stages overlap on the GPU.  The
+ * contexts must be distinct (clone a key that commits twice); they may belong to different curves.  out: `count` commitments in
+ * host memory.  For the two commitments of ONE curve inside RecursiveSNARK::prove_step (comm_W of the fresh witness and the
+ * cross term comm_T of NIFS::prove [R]: both are absorbed before the folding challenge is drawn, neither needs the other;
+ * src/backend/framework.rs:668-675) -- the commitments of the two curves are NOT independent of each other: the secondary
+ * step circuit hashes the primary's folded instance, which contains them.  reef_msm_rows(rows = 2) is the other way to issue
+ * such a pair (one pass of the pipeline over both; same key, equal lengths). */
+reef_status reef_msm_multi(size_t count, reef_msm_ctx *const *ctxs, const reef_fe *const *scalars, const size_t *n, int scalars_loc,
+                           bool is_mont, reef_jacobian *out);
 
 /* K2: rows independent MSMs over the same first row_len bases, plus an optional Pedersen blind:
  *   out[r] = sum_j scalars[r*row_len + j] * bases[j]  (+ blinds[r] * h   if blinds != NULL)

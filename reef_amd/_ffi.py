@@ -84,6 +84,7 @@ def load() -> ctypes.CDLL:
         "reef_msm_ctx_sync": (c_int, [vp]),
         "reef_msm_ctx_stream": (vp, [vp]),
         "reef_msm": (c_int, [vp, vp, c_size_t, c_int, c_bool, vp, c_int]),
+        "reef_msm_multi": (c_int, [c_size_t, POINTER(vp), POINTER(vp), POINTER(c_size_t), c_int, c_bool, vp]),
         "reef_msm_rows": (c_int, [vp, vp, c_size_t, c_size_t, c_int, c_bool, c_uint32, vp, vp, vp, c_int]),
         "reef_msm_rows_symbols": (c_int, [vp, vp, c_size_t, c_size_t, c_int, c_uint32, vp, vp, c_bool, vp, c_int]),
         "reef_ipa_cross_terms": (c_int, [vp, vp, c_size_t, c_int, c_bool, vp, vp, c_size_t, vp, vp]),

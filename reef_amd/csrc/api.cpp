@@ -56,6 +56,14 @@ struct HwQueues {
 } g_hw_queues;
 }  // namespace
 
+// Thread-local destructors of the main thread and static destructors run at process teardown, when HIP may be gone: they look
+// at this flag (set by an atexit hook) and leave the memory to the driver.
+static std::atomic<bool> g_process_exiting{false};
+static void hook_process_exit() {
+    static std::once_flag once;
+    std::call_once(once, [] { atexit([] { g_process_exiting.store(true); }); });
+}
+
 static const CurveVTable *vt(int curve) {
     if (curve == REEF_PALLAS) return pallas_vtable();
     if (curve == REEF_VESTA) return vesta_vtable();
@@ -234,6 +242,38 @@ reef_status reef_msm_rows(reef_msm_ctx *ctx, const reef_fe *scalars, size_t rows
                           uint32_t max_scalar_bits, const reef_fe *blinds, const reef_affine *h, reef_jacobian *out, int out_loc) {
     if (!ctx) { set_error("null argument"); return REEF_ERR_ARG; }
     return guarded([&] { return vt(ctx->curve)->msm_rows(ctx->impl, scalars, rows, row_len, scalars_loc, is_mont, max_scalar_bits, blinds, h, out, out_loc); });
+}
+
+// Several MSMs at once, each on its own context: everything is enqueued first (a context with work in flight keeps its stream,
+// so the next one takes another stream of the pool), then the results are waited for.  The commitments land in host-mapped
+// memory of the calling thread: one wait per context, no copy kernel.
+reef_status reef_msm_multi(size_t count, reef_msm_ctx *const *ctxs, const reef_fe *const *scalars, const size_t *n, int scalars_loc, bool is_mont,
+                           reef_jacobian *out) {
+    if (count == 0) return REEF_OK;
+    if (!ctxs || !scalars || !n || !out || count > 64) { set_error("reef_msm_multi: null argument or more than 64 MSMs"); return REEF_ERR_ARG; }
+    for (size_t i = 0; i < count; ++i) {
+        if (!ctxs[i]) { set_error("null argument"); return REEF_ERR_ARG; }
+        for (size_t j = 0; j < i; ++j)
+            if (ctxs[j] == ctxs[i]) { set_error("reef_msm_multi: contexts must be distinct (clone a key that is used twice)"); return REEF_ERR_ARG; }
+    }
+    static thread_local struct Landing {
+        reef_jacobian *p = nullptr;
+        ~Landing() { if (p && !g_process_exiting.load()) (void)hipHostFree(p); }
+    } land;
+    hook_process_exit();
+    if (!land.p) REEF_HIP_TRY(hipHostMalloc((void **)&land.p, 64 * sizeof(reef_jacobian), hipHostMallocDefault));
+    return guarded([&] {
+        reef_status st = REEF_OK;
+        size_t issued = 0;
+        for (; issued < count && st == REEF_OK; ++issued)
+            st = vt(ctxs[issued]->curve)->msm(ctxs[issued]->impl, scalars[issued], n[issued], scalars_loc, is_mont, land.p + issued, REEF_DEVICE);
+        for (size_t i = 0; i < issued; ++i) {           // wait for whatever was enqueued, also after a failure
+            const reef_status w = vt(ctxs[i]->curve)->ctx_sync(ctxs[i]->impl);
+            if (st == REEF_OK) st = w;
+        }
+        if (st == REEF_OK) memcpy(out, land.p, count * sizeof(reef_jacobian));
+        return st;
+    });
 }
 
 int reef_msm_ctx_byte_tables(reef_msm_ctx *ctx) { return ctx ? vt(ctx->curve)->ctx_byte_tables(ctx->impl) : 0; }
@@ -425,7 +465,6 @@ struct SharedKey {
 };
 std::atomic<size_t> g_cache_bytes{0};
 std::atomic<uint64_t> g_cache_builds{0}, g_cache_hits{0}, g_cache_clones{0}, g_cache_misspeculated{0};
-std::atomic<bool> g_process_exiting{false};   // destructors that run at process teardown must not touch HIP: it may be gone
 SharedKey::~SharedKey() {
     free(host_copy);
     if (g_process_exiting.load()) return;          // the driver reclaims everything
@@ -680,8 +719,7 @@ static reef_status pippenger_cached(int curve, reef_jacobian *out, const reef_af
 
 static reef_status pippenger_try(int curve, reef_jacobian *out, const reef_affine *points, size_t npoints, const reef_fe *scalars, bool is_mont) {
     static const bool cache_on = !(getenv("REEF_MSM_KEY_CACHE") && atoi(getenv("REEF_MSM_KEY_CACHE")) == 0);
-    static std::once_flag exit_hook;
-    std::call_once(exit_hook, [] { atexit([] { g_process_exiting.store(true); }); });
+    hook_process_exit();
     reef_status st = (!cache_on || npoints < KEY_CACHE_MIN_POINTS) ? pippenger_plain(curve, out, points, npoints, scalars, is_mont)
                                                                      : pippenger_cached(curve, out, points, npoints, scalars, is_mont);
     if (st == REEF_ERR_OOM) {                           // give the cache's memory back and serve the call uncached

@@ -433,6 +433,41 @@ static std::string replay_body(const Shape &shape, bool nofold, bool tables, con
         steps_batched_ms = ms_since(tb) / timed_steps * sh->steps;
     }
 
+    // The pair of a curve issued as two CONCURRENT MSMs instead (reef_msm_multi: both enqueued, then both waited for; the second
+    // commitment runs on a clone of the key, i.e. on another stream of the library's pool), and -- an upper bound only, because
+    // the two curves of a step depend on each other through the step circuits -- all four at once.
+    double steps_conc_ms = 0, steps_all4_ms = 0;
+    {
+        reef_msm_ctx *cl[2] = {nullptr, nullptr};
+        for (int k = 0; k < 2; ++k) { CK(reef_msm_ctx_clone(&cl[k], cv[k].key)); owned_ctx.emplace_back(cl[k]); }
+        reef_msm_ctx *pair_ctx[2][2] = {{cv[0].key, cl[0]}, {cv[1].key, cl[1]}};
+        const reef_fe *pair_sc[2][2] = {{hW1.mont.data(), hT1.mont.data()}, {hW2.mont.data(), hT2.mont.data()}};
+        const size_t pair_n[2][2] = {{sh->w1, sh->c1}, {sh->w2, sh->c2}};
+        const reef_fe pair_e[2][2] = {{eW1, eT1}, {eW2, eT2}};
+        reef_jacobian two[2];
+        for (int k = 0; k < 2; ++k) {                    // warm-up (the clones' workspaces) and check
+            CK(reef_msm_multi(2, pair_ctx[k], pair_sc[k], pair_n[k], REEF_HOST, true, two));
+            check_point(cv[k], two[0], pair_e[k][0], "concurrent comm_W");
+            check_point(cv[k], two[1], pair_e[k][1], "concurrent comm_T");
+        }
+        auto tb = clk::now();
+        for (int i = 0; i < timed_steps; ++i) {
+            CK(reef_msm_multi(2, pair_ctx[1], pair_sc[1], pair_n[1], REEF_HOST, true, two));
+            CK(reef_msm_multi(2, pair_ctx[0], pair_sc[0], pair_n[0], REEF_HOST, true, two));
+        }
+        steps_conc_ms = ms_since(tb) / timed_steps * sh->steps;
+        reef_msm_ctx *all_ctx[4] = {cv[1].key, cv[0].key, cl[0], cl[1]};
+        const reef_fe *all_sc[4] = {hT2.mont.data(), hW1.mont.data(), hT1.mont.data(), hW2.mont.data()};
+        const size_t all_n[4] = {sh->c2, sh->w1, sh->c1, sh->w2};
+        reef_jacobian four[4];
+        CK(reef_msm_multi(4, all_ctx, all_sc, all_n, REEF_HOST, true, four));
+        check_point(cv[1], four[0], eT2, "all-four comm_T2");
+        check_point(cv[0], four[2], eT1, "all-four comm_T1");
+        tb = clk::now();
+        for (int i = 0; i < timed_steps; ++i) CK(reef_msm_multi(4, all_ctx, all_sc, all_n, REEF_HOST, true, four));
+        steps_all4_ms = ms_since(tb) / timed_steps * sh->steps;
+    }
+
     auto t_final = clk::now();
     msm(cv[1], hT2, sh->c2);  // last NIFS fold
     int r1 = 0, r2 = 0, r3 = 0;
@@ -563,12 +598,12 @@ static std::string replay_body(const Shape &shape, bool nofold, bool tables, con
            "\"shapes\": \"PREDICTED by Reef's cost model (src/backend/costs.rs restated in oracle/costs_oracle.py, read from %s), not measured on a Reef run\", \"w1\": %zu, \"c1\": %zu, \"w2\": %zu, \"c2\": %zu, "
            "\"scalars\": \"per-step vectors in host memory, commitments returned to the host (PCIe inclusive)\", \"commitments_checked_against_dlog\": %d, "
            "\"key_pallas\": %zu, \"key_vesta\": %zu, \"steps\": %d, \"setup_ms\": %.3f, \"fold_steps_ms\": %.3f, \"ms_per_step\": %.3f, "
-           "\"ms_per_step_batched_pairs\": %.3f, \"pairs_per_step\": %zu, \"final_snark_ms\": %.3f, \"ipa_pallas_ms\": %.3f, \"ipa_pallas_rounds\": %d, \"ipa_vesta_ms\": %.3f, "
+           "\"ms_per_step_batched_pairs\": %.3f, \"ms_per_step_concurrent\": %.3f, \"ms_per_step_all_four_at_once\": %.3f, \"pairs_per_step\": %zu, \"final_snark_ms\": %.3f, \"ipa_pallas_ms\": %.3f, \"ipa_pallas_rounds\": %d, \"ipa_vesta_ms\": %.3f, "
            "\"ipa_vesta_rounds\": %d, \"consistency_ipa_ms\": %.3f, \"consistency_rounds\": %d, \"three_arguments_concurrently_ms\": %.3f, \"total_prove_msm_ms\": %.3f, "
            "\"commit_hyrax_ms\": %.3f, \"commit_hyrax_first_call_ms\": %.3f, \"sumcheck_table_log\": %d, \"sumcheck_ms_per_step\": %.3f, "
            "\"doc_poly_bind_rows_ms\": %.3f, \"total_prove_gpu_ms\": %.3f, \"derive_both_keys_ms\": %.3f, \"commit_merkle_log\": %d, \"commit_merkle_ms\": %.3f, "
            "\"standins\": \"key derivation and Poseidon run on stand-in parameter sets (replay_standins.h), timing only\", \"byte_tables\": %s}",
-           sh->name.c_str(), nofold ? "cross terms over the original key (no generator fold)" : "generator fold per round", shapes_path.c_str(), sh->w1, sh->c1, sh->w2, sh->c2, g_checked, cv[0].n, cv[1].n, sh->steps, setup_ms, steps_ms, steps_ms / sh->steps, steps_batched_ms / sh->steps, pairs_step, final_ms, ipa1_ms, r1, ipa2_ms, r2,
+           sh->name.c_str(), nofold ? "cross terms over the original key (no generator fold)" : "generator fold per round", shapes_path.c_str(), sh->w1, sh->c1, sh->w2, sh->c2, g_checked, cv[0].n, cv[1].n, sh->steps, setup_ms, steps_ms, steps_ms / sh->steps, steps_batched_ms / sh->steps, steps_conc_ms / sh->steps, steps_all4_ms / sh->steps, pairs_step, final_ms, ipa1_ms, r1, ipa2_ms, r2,
            cons_ms, r3, concurrent_ms, steps_ms + final_ms + cons_ms, commit_ms, commit_first_ms, sh->table_log, sc_step_ms, mle_ms,
            steps_ms + final_ms + cons_ms + sh->steps * sc_step_ms + mle_ms, derive_ms, sh->merkle_log, merkle_ms,
            tables ? "\"built with the keys (inside setup_ms): MSMs of 1025..65536 points are sums of table entries\"" : "\"none (bucket pipeline)\"");

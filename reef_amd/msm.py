@@ -273,6 +273,20 @@ class MsmContext:
         return out
 
 
+def msm_multi(ctxs, scalars, is_mont: bool = True) -> np.ndarray:
+    """Several MSMs at once (reef_msm_multi): ctxs[i].msm(scalars[i]) for distinct contexts, host scalars, all enqueued before any
+    is waited for.  Returns the commitments as a (count, 12) array."""
+    lib = _ffi.load()
+    cnt = len(ctxs)
+    arrs = [np.ascontiguousarray(s, dtype=np.uint64) for s in scalars]
+    hs = (ctypes.c_void_p * cnt)(*[c._h for c in ctxs])
+    ps = (ctypes.c_void_p * cnt)(*[a.ctypes.data for a in arrs])
+    ns = (ctypes.c_size_t * cnt)(*[a.shape[0] for a in arrs])
+    out = np.zeros((cnt, 12), dtype=np.uint64)
+    check(lib.reef_msm_multi(cnt, hs, ps, ns, REEF_HOST, bool(is_mont), out.ctypes.data))
+    return out
+
+
 def mult_pippenger(curve, points: np.ndarray, scalars: np.ndarray, is_mont: bool = True) -> np.ndarray:
     """The pasta-msm drop-in symbol (stateless; aborts the process on failure, like the
     reference panics)."""

@@ -137,6 +137,27 @@ def test_attach_moves_a_handle_between_keys(gpu_lib, cref):
         o.close()
 
 
+def test_msm_multi_matches_the_calls_one_by_one(gpu_lib, cref):
+    """reef_msm_multi: the four commitments of a folding step (two per curve, the second of a curve on a clone of its key) enqueued
+    together; same points as one by one, for lengths shorter than the keys; duplicate contexts are refused."""
+    from reef_amd import msm
+    keys = {cid: cref.gen_bases_ap(cid, 800 + cid, 3, 1 << 15) for cid in (0, 1)}
+    ctx = {cid: msm.MsmContext(cid, keys[cid], bucket_groups=1) for cid in (0, 1)}
+    clones = {cid: ctx[cid].clone() for cid in (0, 1)}
+    lens = [(1, 11376), (0, 24918), (0, 24917), (1, 3)]
+    scs = [cref.gen_scalars(cid, 70 + j, n, kind=j % 2) for j, (cid, n) in enumerate(lens)]
+    want = [cref.compress(cid, cref.msm_pippenger(cid, keys[cid][:n].copy(), sc, threads=4)) for (cid, n), sc in zip(lens, scs)]
+    order = [ctx[1], ctx[0], clones[0], clones[1]]
+    for rep in range(3):
+        got = msm.msm_multi(order, scs)
+        assert [msm.compress(cid, got[j]) for j, (cid, _) in enumerate(lens)] == want, rep
+    assert msm.compress(0, msm.msm_multi([clones[0]], [scs[1]])[0]) == want[1]
+    with pytest.raises(msm.ReefError):
+        msm.msm_multi([ctx[0], ctx[0]], [scs[1], scs[2]])
+    for c_ in list(clones.values()) + list(ctx.values()):
+        c_.close()
+
+
 def test_table_turnover_under_concurrency(gpu_lib, cref):
     """More keys than the process-wide table has entries (16), revisited by four threads at once: entries are evicted while other
     threads still hold clones of them; results stay right and the evicted keys' memory is given back."""

@@ -18,7 +18,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def _expected_checks(shape):
     timed_steps = max(shape["steps"], 3)            # the harness times at least three steps
-    return 2 + 4 * timed_steps + 4                  # warm-up W1/W2, four commitments per step, the two batched pairs
+    return 2 + 4 * timed_steps + 4 + 4 + 2          # warm-up W1/W2, four commitments per step, the two batched pairs, the two concurrent pairs, two of the four at once
 
 
 @pytest.mark.parametrize("cfg", ["cfg3", "cfg4"])
@@ -65,6 +65,6 @@ def test_replay_executable(gpu_lib):
     out = subprocess.run([exe, "cfg3", "nofold"], capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
     line = json.loads(out.stdout.strip().splitlines()[-1])
-    assert line["commitments_checked_against_dlog"] >= 18
+    assert line["commitments_checked_against_dlog"] >= 24
     bad = subprocess.run([exe, "cfg3", "nofold", "shapes=/nonexistent.json"], capture_output=True, text=True, timeout=600)
     assert bad.returncode != 0 and "shapes" in bad.stderr
