@@ -381,6 +381,34 @@ def test_full_size_dlog_property(name, logn, kind, groups, gpu_lib):
     assert C.scalar_from_mont(int.from_bytes(sc[12345].tobytes(), "little")) == int.from_bytes(canon[12345].tobytes(), "little")
 
 
+@pytest.mark.parametrize("name,n,kind,bound", [("pallas", (1 << 17) + 12345, 2, 1000), ("vesta", 1 << 18, 2, 3), ("pallas", (1 << 19) - 7, 2, 1 << 40),
+                                               ("vesta", (1 << 17) + 1, 0, 0), ("pallas", 1 << 18, 1, 0)])
+def test_two_level_sort_with_sparse_and_ragged_digits(name, n, kind, bound, gpu_lib):
+    """The sort of large inputs (two levels, one-word entries: round 4) on digit sets that stress where k_accum0 finds its bucket
+    keys: scalars below a small bound (a handful of giant buckets, every other bucket EMPTY: the key of a run is looked up past
+    runs of empty buckets), ragged lengths (the last chunk is short), witness-like and uniform scalars; full-precompute keys as
+    the bench uses them and one bucket group per window.  Expected value: the discrete-log closed form."""
+    from reef_amd import msm
+    C = CURVES[name]
+    k0, d = 0x1234567, 0x891
+    bases = msm.gen_bases(name, k0, d, n, device=True)
+    sc_dev = msm.gen_scalars(name, 0xBEE5, n, kind=kind, small_bound=bound, mont=True, device=True)
+    canon = msm.gen_scalars(name, 0xBEE5, n, kind=kind, small_bound=bound, mont=False)
+    cols = [canon[:, j].astype(object) for j in range(4)]
+    idx = np.arange(n, dtype=object)
+
+    def dlog(upto):
+        acc = 0
+        for j in range(4):
+            acc += (int(np.sum(cols[j][:upto])) * k0 + int(np.sum(cols[j][:upto] * idx[:upto])) * d) << (64 * j)
+        return C.compress(C.mul(acc % C.order, C.gen))
+    for groups, wbits in ((1, 0), (1, 17), (0, 16)):
+        with msm.MsmContext(name, bases, n, bucket_groups=groups, window_bits=wbits) as ctx:
+            assert msm.compress(name, ctx.msm(sc_dev, n)) == dlog(n), (groups, wbits)
+            m = n - 54321
+            assert msm.compress(name, ctx.msm(sc_dev, m)) == dlog(m), (groups, wbits, "prefix")
+
+
 def test_linearity_and_clone_threads(gpu_lib, cref):
     """MSM(a) + MSM(b) == MSM(a+b); clones of one key used from several threads agree."""
     from reef_amd import msm
