@@ -114,3 +114,55 @@ def prover_mle_partial_eval(prods: Sequence[int], x: Sequence[int], es: Sequence
 def verifier_mle_eval(table: Sequence[int], qpt: Sequence[int], q: int = Q) -> int:
     """r1cs_helper.rs:637-641."""
     return prover_mle_partial_eval(table, qpt, list(range(len(table))), True, None, q)[1]
+
+
+# ---- the Fiat-Shamir sponge of a folding step (round 4) -------------------------------------------------------------------
+class Sponge:
+    """neptune's Sponge<F, U4> in Mode::Simplex as Reef drives it through the SpongeAPI [R: the crate is not in the reference tree]:
+    state = [tag, 0, 0, 0, 0] with the tag derived from the IO pattern (src/backend/r1cs.rs:2260-2284: Absorb(k), Squeeze(1), then
+    (Absorb(3), Squeeze(1)) per sum-check round); absorb adds elements into the rate positions 1..4, permuting when they are full;
+    squeeze permutes first if anything was absorbed since the last permutation and reads the rate positions in order.  The permutation
+    is oracle/merkle_oracle.py's (the published Poseidon round structure); constants and tag are the caller's.  PARITY UNPINNED until
+    tests/golden/rust_pin.json exists (tools/rust_pin): tests/test_pin_from_rust.py then replays neptune's own transcript."""
+
+    def __init__(self, params, tag: int):
+        from .merkle_oracle import poseidon_permute
+        self._permute = lambda st: poseidon_permute(st, params)
+        self.p = params
+        self.rate = params.t - 1
+        self.state = [tag % params.m] + [0] * self.rate
+        self.absorb_pos = 0
+        self.squeeze_pos = 0
+        self.dirty = False            # absorbed since the last permutation
+
+    def absorb(self, elems: Sequence[int]) -> None:
+        for e in elems:
+            if self.absorb_pos == self.rate:
+                self.state = self._permute(self.state)
+                self.absorb_pos = 0
+            self.state[1 + self.absorb_pos] = (self.state[1 + self.absorb_pos] + e) % self.p.m
+            self.absorb_pos += 1
+            self.dirty = True
+        self.squeeze_pos = self.rate  # the next squeeze starts from a fresh permutation
+
+    def squeeze(self, n: int = 1) -> List[int]:
+        out = []
+        for _ in range(n):
+            if self.dirty or self.squeeze_pos == self.rate:
+                self.state = self._permute(self.state)
+                self.absorb_pos = 0
+                self.squeeze_pos = 0
+                self.dirty = False
+            out.append(self.state[1 + self.squeeze_pos])
+            self.squeeze_pos += 1
+        return out
+
+
+def linear_mle_product(table_t: List[int], table_eq: List[int], ell: int, i: int, sponge: Sponge, q: int = Q) -> Tuple[int, int, int, int]:
+    """The whole of linear_mle_product (r1cs_helper.rs:441-506): sums, absorb (con, x, xsq) in that order (:478-482), squeeze the
+    challenge (:485-488), fold both tables.  Returns (r_i, xsq, x, con) like the reference."""
+    xsq, x, con = linear_mle_coeffs(table_t, table_eq, ell, i, q)
+    sponge.absorb([con, x, xsq])
+    r_i = sponge.squeeze(1)[0]
+    linear_mle_fold(table_t, table_eq, ell, i, r_i, q)
+    return r_i, xsq, x, con
