@@ -176,3 +176,158 @@ def sharded_rows(local_rows: Callable[[int, int], np.ndarray], rows: int, width:
         a, b = shard_bounds(rows, world, r)
         res[a:b] = out[r].numpy().view(np.uint64)[: b - a]
     return res
+
+
+# ---- independent units over devices (round 4) -----------------------------------------------------------------
+# Reef's own MSMs are 2^14..2^16 points and must not be split: what a multi-GPU node can take from a --prove run is
+# WHOLE units that do not depend on each other -- the final SNARK's three arguments (the two Spartan inner-product arguments and
+# the consistency argument, src/backend/framework.rs:695-721), the rows of the document commitment (`sharded_rows`) -- and, for
+# memory rather than time, the two curves of a folding step (their commitments depend on each other through the step circuits,
+# include/reef_msm.h reef_msm_multi: placing the secondary curve's key on another device frees HBM, it does not overlap them).
+def place_units(costs: Sequence[float], world: int) -> List[int]:
+    """owner[u] for independent units of the given relative costs: longest unit first onto the least loaded rank (ties: lowest
+    rank), deterministic, identical on every rank.  Three arguments of costs (5.4, 4.4, 2.9) ms on 2 ranks -> [0, 1, 1]."""
+    load = [0.0] * max(world, 1)
+    owner = [0] * len(costs)
+    for u in sorted(range(len(costs)), key=lambda k: (-costs[k], k)):
+        r = min(range(len(load)), key=lambda k: (load[k], k))
+        owner[u] = r
+        load[r] += costs[u]
+    return owner
+
+
+def run_placed_units(run_unit: Callable[[int], np.ndarray], widths: Sequence[int], costs: Sequence[float], group=None) -> List[np.ndarray]:
+    """Every rank runs the units `place_units` gives it (`run_unit(u)` -> uint64 array of widths[u] words: an argument's L/R
+    points, a commitment ...) and ONE all-gather hands every result to every rank, in unit order.  Payloads are a few KiB."""
+    import torch
+    import torch.distributed as dist
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    owner = place_units(costs, world)
+    per_rank = [sum(widths[u] for u in range(len(widths)) if owner[u] == r) for r in range(world)]
+    buf = np.zeros(max(max(per_rank), 1), dtype=np.uint64)
+    off = 0
+    for u in range(len(widths)):
+        if owner[u] == rank:
+            res = np.ascontiguousarray(run_unit(u), dtype=np.uint64).reshape(-1)
+            if res.shape[0] != widths[u]:
+                raise ValueError(f"unit {u} returned {res.shape[0]} words, {widths[u]} expected")
+            buf[off:off + widths[u]] = res
+            off += widths[u]
+    t = torch.from_numpy(buf.view(np.int64).copy())
+    out = [torch.empty_like(t) for _ in range(world)]
+    dist.all_gather(out, t, group=group)
+    offs = [0] * world
+    results: List[np.ndarray] = []
+    for u in range(len(widths)):
+        r = owner[u]
+        results.append(out[r].numpy().view(np.uint64)[offs[r]:offs[r] + widths[u]].copy())
+        offs[r] += widths[u]
+    return results
+
+
+class LowBitShardedSumCheck:
+    """The nlookup sum-check of one folding step (row N2; src/backend/r1cs_helper.rs:441-544) with the table sharded over the ranks
+    by the LOW index bits: rank r keeps the entries i with i mod N = r (N a power of two, k = log2 N), as a local table of 2^(ell-k)
+    entries indexed by i >> k.  A round folds the TOP index bit (pairs b, b + pow), which both live on the same rank, so every fold is
+    rank-local; a round exchanges the three partial sums (3 x 32 B per rank, one all-gather), every rank adds them and derives the SAME
+    challenge from the same transcript.  After ell - k rounds a rank holds one entry of T and of EQ; the last k rounds run on the N
+    gathered entries, identically on every rank.
+
+    gen_eq_table for the shard: EQ[i] = masses + rs_last * prod_j eq(bit_j(i), last_q[j]) (:508-544) with bit j paired with
+    last_q[j]; the k low bits of a local entry are the rank's, so their factors are a constant of the rank that goes into rs_last,
+    and local bit j' pairs with last_q[j' + k].  A mass at q belongs to rank q mod N, at local index q >> k.
+
+    `engine`: an object with the methods of reef_amd.sumcheck.SumCheck for a table of 2^(ell-k) entries (on the GPU: that class;
+    in the CPU tests: the oracle behind the same names).  `finish_rounds(t, e, rounds) -> transcript tail` runs the last k rounds
+    on N-entry tables (the oracle's linear_mle functions on the host: 2 N entries)."""
+
+    def __init__(self, engine, ell: int, modulus: int, group=None):
+        import torch.distributed as dist
+        self.dist, self.group = dist, group
+        self.world, self.rank = dist.get_world_size(group), dist.get_rank(group)
+        self.k = self.world.bit_length() - 1
+        if 1 << self.k != self.world or self.k > ell:
+            raise ValueError("the low-bit shard needs a power-of-two number of ranks, at most 2^ell")
+        self.engine, self.ell, self.q = engine, ell, modulus
+
+    def local_table(self, table: Sequence[int]) -> List[int]:
+        """The rank's shard of a full table (zero-padded to 2^ell as the reference pads, r1cs.rs:2323-2330)."""
+        n = 1 << self.ell
+        return [table[i] if i < len(table) else 0 for i in range(self.rank, n, self.world)]
+
+    def set_table(self, table: Sequence[int]) -> None:
+        self.engine.set_table(0, self.local_table(table))
+
+    def gen_eq_table(self, rs: Sequence[int], qs: Sequence[int], last_q: Sequence[int]) -> None:
+        q, k = self.q, self.k
+        const = rs[len(qs)] % q
+        for j in range(k):
+            bit = (self.rank >> j) & 1
+            const = const * (last_q[j] if bit else (1 - last_q[j])) % q
+        mine = [(qq >> k, rr) for qq, rr in zip(qs, rs) if qq & (self.world - 1) == self.rank]
+        self.engine.gen_eq_table([rr for _, rr in mine] + [const], [qq for qq, _ in mine], list(last_q[k:]))
+
+    def _allsum3(self, triple: Sequence[int]) -> Tuple[int, int, int]:
+        import torch
+        words = np.zeros(12, dtype=np.uint64)
+        for a, v in enumerate(triple):
+            for j in range(4):
+                words[4 * a + j] = (v >> (64 * j)) & 0xFFFFFFFFFFFFFFFF
+        t = torch.from_numpy(words.view(np.int64).copy())
+        out = [torch.empty_like(t) for _ in range(self.world)]
+        self.dist.all_gather(out, t, group=self.group)
+        tot = [0, 0, 0]
+        for o in out:
+            w = o.numpy().view(np.uint64)
+            for a in range(3):
+                tot[a] += sum(int(w[4 * a + j]) << (64 * j) for j in range(4))
+        return tot[0] % self.q, tot[1] % self.q, tot[2] % self.q
+
+    def run_step(self, challenge: Callable[[int, int, int, int], int]) -> Tuple[List[Tuple[int, int, int]], List[int], int, int]:
+        """All ell rounds.  `challenge(i, xsq, x, con)` is the host's transcript (Poseidon sponge; every rank holds the same one).
+        -> (coefficient triples per round, challenges, T~(r), EQ~(r)), identical on every rank."""
+        import torch
+        ell, k, eng = self.ell, self.k, self.engine
+        local = ell - k
+        coeffs, rs_out = [], []
+        g = eng.round_coeffs(1) if local >= 1 else None
+        for i in range(1, local + 1):
+            tot = self._allsum3(g)
+            r = challenge(i, *tot)
+            coeffs.append(tot)
+            rs_out.append(r)
+            if i < local:
+                g = eng.fold_and_next_coeffs(i, r)
+            else:
+                eng.fold(i, r)
+        t_loc = eng.read(0, 1)[0] if local >= 1 else eng.read(0, 1)[0]
+        e_loc = eng.read(1, 1)[0]
+        # the last k rounds: the N surviving entries, entry r on rank r (index bits = the rank), gathered and finished everywhere
+        words = np.zeros(8, dtype=np.uint64)
+        for a, v in enumerate((t_loc, e_loc)):
+            for j in range(4):
+                words[4 * a + j] = (v >> (64 * j)) & 0xFFFFFFFFFFFFFFFF
+        t = torch.from_numpy(words.view(np.int64).copy())
+        out = [torch.empty_like(t) for _ in range(self.world)]
+        self.dist.all_gather(out, t, group=self.group)
+        tt, ee = [], []
+        for o in out:
+            w = o.numpy().view(np.uint64)
+            tt.append(sum(int(w[j]) << (64 * j) for j in range(4)))
+            ee.append(sum(int(w[4 + j]) << (64 * j) for j in range(4)))
+        for i in range(1, k + 1):
+            pow_ = 1 << (k - i)
+            xsq = x = con = 0
+            for b in range(pow_):
+                ts, es = tt[b + pow_] - tt[b], ee[b + pow_] - ee[b]
+                xsq += ts * es
+                x += es * tt[b] + ts * ee[b]
+                con += tt[b] * ee[b]
+            tot = (xsq % self.q, x % self.q, con % self.q)
+            r = challenge(local + i, *tot)
+            coeffs.append(tot)
+            rs_out.append(r)
+            for b in range(pow_):
+                tt[b] = (tt[b] * (1 - r) + tt[b + pow_] * r) % self.q
+                ee[b] = (ee[b] * (1 - r) + ee[b + pow_] * r) % self.q
+        return coeffs, rs_out, tt[0], ee[0]

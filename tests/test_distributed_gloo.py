@@ -126,3 +126,104 @@ def test_signed_digits_recompose_and_split():
         for world in (1, 2, 3, 8):
             owned = [D.owned_windows(W, world, r) for r in range(world)]
             assert sorted(w for o in owned for w in o) == list(range(W))
+
+
+# ---- round 4: independent units over ranks, and the sum-check table sharded by low index bits -------------------------------
+class _OracleSumCheck:
+    """The oracle behind the method names of reef_amd.sumcheck.SumCheck (what LowBitShardedSumCheck drives on the GPU)."""
+
+    def __init__(self, ell):
+        from oracle import sumcheck_oracle as S
+        self.S, self.ell, self.t, self.e = S, ell, None, None
+
+    def set_table(self, which, values):
+        v = list(values) + [0] * ((1 << self.ell) - len(values))
+        if which == 0:
+            self.t = v
+        else:
+            self.e = v
+
+    def gen_eq_table(self, rs, qs, last_q):
+        self.e = self.S.gen_eq_table(list(rs), list(qs), list(last_q)) if self.ell else [rs[-1] % self.S.Q]
+
+    def round_coeffs(self, i):
+        return self.S.linear_mle_coeffs(self.t, self.e, self.ell, i)
+
+    def fold(self, i, r):
+        self.S.linear_mle_fold(self.t, self.e, self.ell, i, r)
+
+    def fold_and_next_coeffs(self, i, r):
+        self.fold(i, r)
+        return self.round_coeffs(i + 1)
+
+    def read(self, which, count):
+        return (self.t if which == 0 else self.e)[:count]
+
+
+def _challenge(i, xsq, x, con):
+    import hashlib
+    from oracle.sumcheck_oracle import Q
+    h = hashlib.sha256(b"%d|%x|%x|%x" % (i, con, x, xsq)).digest()          # absorbed in the reference's order (con, x, xsq)
+    return int.from_bytes(h, "little") % Q
+
+
+def _worker_units(rank, world, port, results):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from oracle import sumcheck_oracle as S
+        from oracle.pasta_oracle import SplitMix64, uniform_scalar
+        # (1) three independent units of different sizes and costs: every rank ends up with all results, each computed once
+        widths, costs = [24 * 5, 24 * 4, 24 * 2], [5.4, 4.4, 2.9]
+        ran = []
+
+        def run_unit(u):
+            ran.append(u)
+            return np.arange(widths[u], dtype=np.uint64) * (u + 1) + 1000 * u
+        got = D.run_placed_units(run_unit, widths, costs)
+        units_ok = all((got[u] == np.arange(widths[u], dtype=np.uint64) * (u + 1) + 1000 * u).all() for u in range(3))
+        owner = D.place_units(costs, world)
+        units_ok = units_ok and sorted(ran) == [u for u in range(3) if owner[u] == rank]
+        # (2) one folding step of the sum-check with the table sharded by low index bits against the single-rank transcript
+        ell, nq = 7, 5
+        rng = SplitMix64(99)
+        table = [uniform_scalar(rng, S.Q) if i % 3 else i % 7 for i in range((1 << ell) - 9)]      # ragged: zero padding at the end
+        qs = [rng.next() % (1 << ell) for _ in range(nq)]
+        qs[0], qs[1] = 1, (1 << ell) - 2                                                             # one mass on each rank
+        rs = [uniform_scalar(rng, S.Q) for _ in range(nq + 1)]
+        last_q = [uniform_scalar(rng, S.Q) for _ in range(ell)]
+        sh = D.LowBitShardedSumCheck(_OracleSumCheck(ell - (world.bit_length() - 1)), ell, S.Q)
+        sh.set_table(table)
+        sh.gen_eq_table(rs, qs, last_q)
+        coeffs, chal, t_fin, e_fin = sh.run_step(_challenge)
+        tt = table + [0] * ((1 << ell) - len(table))
+        ee = S.gen_eq_table(rs, qs, last_q)
+        want = []
+        for i in range(1, ell + 1):
+            c3 = S.linear_mle_coeffs(tt, ee, ell, i)
+            want.append(c3)
+            S.linear_mle_fold(tt, ee, ell, i, _challenge(i, *c3))
+        results[rank] = (units_ok, coeffs == want, (t_fin, e_fin) == (tt[0], ee[0]), chal == [_challenge(i + 1, *c) for i, c in enumerate(want)])
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_independent_units_and_low_bit_sharded_sumcheck(world):
+    mgr = mp.Manager()
+    results = mgr.dict()
+    mp.spawn(_worker_units, args=(world, _free_port(), results), nprocs=world, join=True)
+    assert len(results) == world
+    for r in range(world):
+        assert results[r][0], "placed units: a result is wrong or a unit ran on the wrong rank"
+        assert results[r][1], "sharded sum-check: round coefficients differ from the single-rank transcript"
+        assert results[r][2], "sharded sum-check: final T~(r), EQ~(r) differ"
+        assert results[r][3], "sharded sum-check: challenges differ"
+
+
+def test_place_units_is_deterministic_and_balanced():
+    assert D.place_units([5.4, 4.4, 2.9], 1) == [0, 0, 0]
+    assert D.place_units([5.4, 4.4, 2.9], 2) == [0, 1, 1]          # the final SNARK's three arguments (cfg3, ms) on two GPUs: 5.4 | 7.3
+    assert D.place_units([5.4, 4.4, 2.9], 3) == [0, 1, 2] == D.place_units([5.4, 4.4, 2.9], 8)
+    assert D.place_units([], 4) == []
