@@ -269,6 +269,108 @@ def replay_cpu_leg(out, cfg="cfg3", cpu_threads=None):
                 "cpu_ipa_ms": c["ipa_pallas_ms"] + c["ipa_vesta_ms"], "cpu_consistency_ipa_ms": c["consistency_ipa_ms"], "cores": c["threads"], "cpu_kind": c["kind"]})
 
 
+def independent_units_legs(a, rank, world, dist):
+    """After the timed region of an N > 1 run, never `value`.  (1) final_snark_ms: three inner-product arguments without generator folds
+    (reef_ipa_cross_terms on resident keys of cfg4's sizes: 2^16 Pallas, 2^14 Vesta, 2^13 Hyrax row generators) dealt out whole by
+    reef_amd.distributed.place_units, one all-gather of their L/R points; beside it rank 0 running all three one after the other.
+    (2) sumcheck_ms_per_step: one folding step over a 2^26-entry table (cfg4's ell) sharded by low index bits
+    (LowBitShardedSumCheck): rank-local folds, 96 B of partial coefficients per rank and round."""
+    import numpy as np
+    import torch
+    from reef_amd import msm
+    from reef_amd import distributed as D
+    from reef_amd.sumcheck import SumCheck
+    hg = dist.new_group(backend="gloo") if dist.get_backend() != "gloo" else None
+    out = {}
+
+    def max_over_ranks(sec):
+        t = torch.tensor([sec], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=hg)
+        return float(t.item())
+
+    # ---- (1) the three arguments
+    sizes = [("pallas", 1 << 16), ("vesta", 1 << 14), ("pallas", 1 << 13)]
+    costs = [7.2, 4.4, 3.7]                                   # ms alone on one MI355X (profiles/r03_replay_prove_msm.jsonl, cfg4)
+    owner = D.place_units(costs, world)
+    rounds = [n.bit_length() - 1 for _, n in sizes]
+    widths = [r * 24 for r in rounds]
+    keys, vecs = {}, {}
+    for u, (cv, n) in enumerate(sizes):
+        if owner[u] == rank or rank == 0:                     # rank 0 also holds all three for the one-GPU figure
+            bases = msm.gen_bases(cv, 0xC0FFEE + u, 7, n, device=True)
+            keys[u] = msm.MsmContext(cv, bases, n, bucket_groups=1)
+            vecs[u] = msm.gen_scalars(cv, 40 + u, n, kind=0, mont=True)
+
+    def run_unit(u):
+        ctx, v, res = keys[u], vecs[u], []
+        w1s, w2s, ln = [], [], sizes[u][1]
+        while ln > 1:
+            L, R = ctx.ipa_cross_terms(v[:ln], w1s, w2s)
+            res += [L, R]
+            w1s.append(0x1234567890abcdef + len(w1s)); w2s.append(0x0badc0ffee0ddf00 + len(w2s))
+            ln //= 2
+        return np.concatenate(res)
+    for u in keys:
+        run_unit(u)                                           # warm-up: workspaces
+    dist.barrier(group=hg)
+    t0 = time.perf_counter()
+    got = D.run_placed_units(run_unit, widths, costs, group=hg)
+    placed = max_over_ranks(time.perf_counter() - t0)
+    one_gpu = None
+    if rank == 0:
+        t0 = time.perf_counter()
+        ref = [run_unit(u) for u in range(3)]
+        one_gpu = time.perf_counter() - t0
+        # the points computed on other ranks are the ones rank 0 computes itself (compared in the canonical encoding: Jacobian
+        # representatives depend on the order the sort's atomics happened to take)
+        same = all(msm.compress(sizes[u][0], ref[u].reshape(-1, 12)) == msm.compress(sizes[u][0], got[u].reshape(-1, 12)) for u in range(3))
+    else:
+        same = True
+    out["final_snark"] = {"arguments": [f"{cv} 2^{n.bit_length() - 1}" for cv, n in sizes], "owner": owner, "ms": placed * 1e3,
+                          "one_gpu_one_after_the_other_ms": one_gpu * 1e3 if one_gpu else None, "check": "same-points" if same else "MISMATCH",
+                          "note": "three whole arguments dealt out by cost (place_units), one host-staged all-gather of their L/R points; driven from Python with the "
+                                  "vectors in host memory (the C++ harness reads 7.2 + 4.4 + 3.7 ms one after the other on one GPU)"}
+    for k in keys.values():
+        k.close()
+
+    # ---- (2) one sum-check step, table sharded by low index bits
+    ell = 26
+    kbits = world.bit_length() - 1
+    if 1 << kbits == world:
+        Q = msm.PALLAS_SCALAR_Q
+        loc = ell - kbits
+        with SumCheck("pallas", loc) as eng:
+            shard = msm.gen_scalars("pallas", 0xD0C + rank, 1 << loc, kind=0, mont=False, device=True)   # the rank's entries i = rank (mod N)
+            eng.set_table_device(0, shard.ptr, 1 << loc)
+            sh = D.LowBitShardedSumCheck(eng, ell, Q, group=hg)
+            nq = 33
+            rs = [(0x1234567 * (k + 3)) % Q for k in range(nq + 1)]
+            qs = [(0x9E3779B1 * (k + 1)) % (1 << ell) for k in range(nq)]
+            last_q = [(0x7654321 * (k + 5)) % Q for k in range(ell)]
+            chal = lambda i, xsq, x, con: (con * 3 + x * 5 + xsq * 7 + i) % Q      # stands in for the Poseidon sponge (same on every rank)
+            best, ident = None, True
+            for rep in range(3):
+                eng.reset_table()
+                dist.barrier(group=hg)
+                t0 = time.perf_counter()
+                sh.gen_eq_table(rs, qs, last_q)
+                coeffs, cs, t_fin, e_fin = sh.run_step(chal)
+                dt = max_over_ranks(time.perf_counter() - t0)
+                best = dt if best is None else min(best, dt)
+                claim = None                                   # the sum-check identity round after round: g_i(0) + g_i(1) = g_{i-1}(r_{i-1})
+                for (xsq, x, con), r in zip(coeffs, cs):
+                    if claim is not None:
+                        ident = ident and (2 * con + x + xsq) % Q == claim
+                    claim = (xsq * r * r + x * r + con) % Q
+                ident = ident and claim == t_fin * e_fin % Q
+            shard.free()
+        out["sumcheck"] = {"ell": ell, "entries_per_rank": 1 << loc, "ms_per_step": best * 1e3, "check": "sumcheck-identity-ok" if ident else "MISMATCH",
+                           "note": "gen_eq_table + all rounds; folds are rank-local, a round exchanges 3 x 32 B per rank (host-staged: the challenge is the host's)"}
+    else:
+        out["sumcheck"] = {"skipped": "the low-bit shard needs a power-of-two number of ranks"}
+    return out
+
+
 def main():
     a = parse()
     rank = int(os.environ.get("RANK", "0"))
@@ -531,6 +633,14 @@ def main():
         except Exception as e:
             print(f"[bench] strong-scaling legs failed on rank {rank}: {e}", file=sys.stderr)
             strong, strong_results = {"error": str(e)}, {}
+        # (round 4) the work Reef's cfg4 really does, placed over the ranks as WHOLE units: the final SNARK's three
+        # arguments (src/backend/framework.rs:695-721) and one folding step's sum-check with its table sharded by low index bits
+        # (r1cs_helper.rs:441-544).  Their tiny exchanges feed the HOST's transcript, so they go through a gloo group.
+        if isinstance(strong, dict) and "error" not in strong and os.environ.get("REEF_BENCH_UNITS", "1") != "0":
+            try:
+                strong.update(independent_units_legs(a, rank, world, dist))
+            except Exception as e:
+                strong["independent_units_error"] = str(e)
 
     # ---- after the timed region (none of this is `value`) ------------------------------------------------
     # (1) the accumulation kernel with ONE MSM in flight: with several MSMs sharing the chip a launch is stretched by
