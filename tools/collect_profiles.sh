@@ -49,3 +49,8 @@ bash $root/tools/batch_sweep.sh $out/${R}_batch_sweep.txt > /dev/null 2>&1
  echo "## a thread per node"; REEF_POSEIDON_SPREAD=0 python $root/tools/time_merkle.py 10 14 16 18 20 22 | grep symbols) > $out/${R}_merkle_spread.txt 2>&1
 (for f in 1 0; do echo "REEF_MSM_FUSE_MERGE=$f"; REEF_MSM_FUSE_MERGE=$f python $root/tools/sweep_plans.py 12 14 15 16 17 2>&1 | grep "##" | grep "G=1"; done) > $out/${R}_fused_merge_ab.txt 2>&1
 python $root/tools/pmc_streaming.py $out/${R}_pmc_streaming.json > /dev/null 2>&1
+# round 4 additions
+python $root/tools/time_stateless.py --threads 1,4,8 > $out/${R}_stateless_concurrent.txt 2>&1
+python $root/tools/time_concurrent_ipa.py > $out/${R}_concurrent_ipa.txt 2>&1
+python $root/tools/time_poseidon_latency.py > $out/${R}_poseidon_latency_raw.txt 2>&1
+for m in fresh contexts-alive threads-leftover torch-first; do python $root/tools/diag_queues2.py $m 2>&1 | grep -v amdgpu.ids; done > $out/${R}_concurrency_after.txt
