@@ -39,3 +39,4 @@ with SumCheck("pallas", ell) as sc:
         sc.fold_and_next_coeffs(i, (0x1234567 * i) % Q)
         t.append(time.perf_counter() - t0)
     print(f"small sum-check rounds (2^{ell} entries and below), fold + next coefficients, host to host: median {sorted(t)[len(t) // 2] * 1e6:.1f} us, min {min(t) * 1e6:.1f} us")
+    print("   per round, pow = 2^13 .. 2: " + " ".join(f"{v * 1e6:.0f}" for v in t) + f" us; sum {sum(t) * 1e6:.0f} us")
