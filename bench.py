@@ -280,7 +280,9 @@ def independent_units_legs(a, rank, world, dist):
     from reef_amd import msm
     from reef_amd import distributed as D
     from reef_amd.sumcheck import SumCheck
-    hg = dist.new_group(backend="gloo") if dist.get_backend() != "gloo" else None
+    import datetime
+    # a rank that fails before a collective must not leave the others waiting for the default half hour
+    hg = dist.new_group(backend="gloo", timeout=datetime.timedelta(seconds=180))
     out = {}
 
     def max_over_ranks(sec):
@@ -771,7 +773,8 @@ def main():
                                     else "HOST-STAGED gloo all_gather of 96 B partials (debug fallback, not RCCL) + on-device add"),
                        "check": check, "partials_differ_from_total": partials_differ, "msm_ms_stream": tot_ms,
                        "strong_scaling": strong,
-                       "rccl": ({"ranks_seen": dist.get_world_size(), "backend": a.backend, "stream_ordered": stream_ordered} if multi else None)},
+                       "rccl": ({"ranks_seen": dist.get_world_size(), "backend": a.backend, "stream_ordered": stream_ordered} if multi else None),
+                       "streams_of_the_contexts": (len({c_.stream for c_ in ctxs}) if multi else None)},
             "roofline": {"bound": "hbm", "kernel": "k_accum0 (bucket accumulation)", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": traffic,
                          "traffic_source": traffic_src,

@@ -68,6 +68,7 @@ struct PoolStream {
     hipStream_t s = nullptr;
     int device = 0;
     std::atomic<int> active{0};      // callers between their first enqueue and the wait that found them idle again
+    std::atomic<int> pins{0};        // contexts whose stream was handed to the caller (reef_msm_ctx_stream): they stay here for life
 };
 struct StreamPool {
     std::mutex mu;
@@ -100,6 +101,35 @@ struct StreamPool {
             }
         }
         best->active.fetch_add(1, std::memory_order_relaxed);
+        *out = best;
+        return REEF_OK;
+    }
+    // a stream for a context that will STAY on it (its stream is handed to the caller, e.g. for RCCL ordering): the one with the
+    // fewest such contexts, then the fewest callers at work -- three pinned contexts of a bench rank must not share one stream
+    reef_status pick_for_pin(int device, PoolStream **out) {
+        std::lock_guard<std::mutex> lk(mu);
+        PoolStream *best = nullptr;
+        size_t on_device = 0;
+        auto load = [](PoolStream *p) { return 1000 * p->pins.load(std::memory_order_relaxed) + p->active.load(std::memory_order_relaxed); };
+        for (PoolStream *p : streams)
+            if (p->device == device) {
+                ++on_device;
+                if (!best || load(p) < load(best)) best = p;
+            }
+        if (!best || (load(best) > 0 && on_device < limit())) {
+            PoolStream *p = new PoolStream();
+            p->device = device;
+            hipError_t e = hipStreamCreateWithFlags(&p->s, hipStreamNonBlocking);
+            if (e != hipSuccess) {
+                delete p;
+                if (!best) { set_error("hipStreamCreate: %s", hipGetErrorString(e)); return REEF_ERR_HIP; }
+                (void)hipGetLastError();
+            } else {
+                streams.push_back(p);
+                best = p;
+            }
+        }
+        best->pins.fetch_add(1, std::memory_order_relaxed);
         *out = best;
         return REEF_OK;
     }
@@ -149,6 +179,20 @@ struct StreamLease {
     void idle() {
         if (counted) StreamPool::leave(ps);
         counted = false;
+    }
+    // from now on the context stays on one stream; only from idle (the caller of reef_msm_ctx_stream has waited for its work)
+    reef_status pin(int device, hipStream_t *stream) {
+        if (!pinned) {
+            if (counted) { *stream = ps->s; pinned = true; ps->pins.fetch_add(1, std::memory_order_relaxed); return REEF_OK; }   // work in flight: this stream it is
+            REEF_TRY(stream_pool().pick_for_pin(device, &ps));
+            pinned = true;
+        }
+        *stream = ps->s;
+        return REEF_OK;
+    }
+    void unpin() {
+        if (pinned && ps) ps->pins.fetch_sub(1, std::memory_order_relaxed);
+        pinned = false;
     }
 };
 

@@ -158,6 +158,24 @@ def test_msm_multi_matches_the_calls_one_by_one(gpu_lib, cref):
         c_.close()
 
 
+def test_contexts_whose_stream_is_handed_out_get_streams_of_their_own(gpu_lib, cref):
+    """reef_msm_ctx_stream pins a context to a stream of the library's pool (RCCL / torch order their work after it): the three
+    contexts a bench rank keeps in flight must not end up on ONE stream, and a pinned context keeps its stream across calls."""
+    from reef_amd import msm
+    bases = cref.gen_bases_ap(0, 5, 3, 4096)
+    sc = cref.gen_scalars(0, 6, 4096)
+    want = cref.compress(0, cref.msm_pippenger(0, bases, sc, threads=4))
+    with msm.MsmContext(0, bases, bucket_groups=1) as ctx:
+        clones = [ctx.clone() for _ in range(2)]
+        streams = [c.stream for c in [ctx] + clones]
+        assert len(set(streams)) == 3 and all(streams)
+        for c, s in zip([ctx] + clones, streams):
+            assert msm.compress(0, c.msm(sc)) == want
+            assert c.stream == s
+        for c in clones:
+            c.close()
+
+
 def test_table_turnover_under_concurrency(gpu_lib, cref):
     """More keys than the process-wide table has entries (16), revisited by four threads at once: entries are evicted while other
     threads still hold clones of them; results stay right and the evicted keys' memory is given back."""

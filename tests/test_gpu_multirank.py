@@ -45,6 +45,7 @@ def test_bench_with_two_ranks(sharding, logn, gpu_lib):
     assert cfg["partials_differ_from_total"] is True             # each rank really held a partial sum
     assert "gloo" in cfg["exchange"]                             # labelled as the host-staged fallback, not as RCCL
     assert cfg["rccl"] == {"ranks_seen": 2, "backend": "gloo", "stream_ordered": False}
+    assert cfg["streams_of_the_contexts"] == cfg["streams"]       # contexts whose stream is handed out sit on streams of their own
     if sharding == "points":
         assert line["scaling"] == "weak" and cfg["total_points"] == 2 << logn and cfg["sharding"] == "points"
         # one SCALE run yields both strong splits as well: ONE 2^logn-point MSM by window and by points on the same ranks,
