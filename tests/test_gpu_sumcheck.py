@@ -345,6 +345,62 @@ def test_structured_pristine_table_vs_oracle(kind, ell, nq, fused, gpu_lib, monk
         assert sc.round_coeffs(1) == linear_mle_coeffs(t, e, ell, 1, q)
 
 
+@pytest.mark.parametrize("kind,ell,nq", [("hybrid", 10, 7), ("hybrid", 12, 33), ("document", 8, 5), ("document", 11, 20), ("mixed", 10, 9), ("mixed", 13, 17),
+                                         ("hybrid", 6, 2), ("hybrid", 7, 3)])
+@pytest.mark.parametrize("interrupt", ["none", "read", "unfused", "coeffs", "set_eq"])
+def test_deferred_first_fold(kind, ell, nq, interrupt, gpu_lib, monkeypatch):
+    """Round 4: the first fold of a structured table is deferred by one round for the rows whose next fold has only constant / small
+    sources too -- round two's sums come from the pristine rows with scaled row factors, the second fold writes a quarter-size table
+    straight from the 4-byte sources.  Every round's coefficients against the oracle with NOTHING read in between (so that the
+    second fold really takes the deferred path), masses planted in deferred rows, and the calls that are not a second fold -- a
+    read of T, an unfused fold, stand-alone coefficients, a new EQ table -- right after the first fold: the table is written out
+    after all and the step goes on as the reference's."""
+    from reef_amd.sumcheck import SumCheck
+    monkeypatch.setenv("REEF_SC_RANK1_MIN_POW", "1")
+    q = Q
+    rng = SplitMix64(ell * 7919 + nq + len(interrupt))
+    t = _structured_table(kind, ell, rng, q)
+    n = 1 << ell
+    qs = [rng.next() % n for _ in range(nq)]
+    qs[0], qs[-1] = n - 1, n // 2 + 1                           # masses in the (small / constant) second half
+    rs = [uniform_scalar(rng, q) for _ in range(nq + 1)]
+    last_q = [uniform_scalar(rng, q) for _ in range(ell)]
+    e = gen_eq_table(rs, qs, last_q, q)
+    for defer in ("1", "0"):
+        monkeypatch.setenv("REEF_SC_DEFER", defer)
+        with SumCheck("pallas", ell) as sc:
+            sc.set_table(0, t)
+            for step in range(2):
+                tt, ee = list(t), list(e)
+                sc.reset_table()
+                sc.gen_eq_table(rs, qs, last_q)
+                g = sc.round_coeffs(1)
+                i = 1
+                while i <= ell:
+                    assert g == linear_mle_coeffs(tt, ee, ell, i, q), (kind, defer, step, i)
+                    r = uniform_scalar(rng, q) if i != 2 else (q - 1, 0)[step]      # the second fold with the edge challenges
+                    linear_mle_fold(tt, ee, ell, i, r, q)
+                    live = 1 << (ell - i)
+                    if i == 1 and step == 0 and interrupt == "unfused":
+                        sc.fold(i, r)                                # not a fused call: nothing is deferred
+                        g = sc.round_coeffs(i + 1)
+                    elif i < ell:
+                        g = sc.fold_and_next_coeffs(i, r)
+                    else:
+                        sc.fold(i, r)
+                    if i == 1 and step == 0:
+                        if interrupt == "read":
+                            assert sc.read(0, live) == tt[:live], (kind, defer)
+                        elif interrupt == "coeffs":
+                            assert sc.round_coeffs(2) == linear_mle_coeffs(tt, ee, ell, 2, q)
+                        elif interrupt == "set_eq" and ell > 1:
+                            sc.set_table(1, ee[:live] + [0] * live)   # the folded EQ handed back as a dense table: same values
+                            assert sc.round_coeffs(2) == linear_mle_coeffs(tt, ee, ell, 2, q)
+                            g = sc.round_coeffs(2)
+                    i += 1
+                assert sc.read(0, 1) == [tt[0]] and sc.read(1, 1) == [ee[0]], (kind, defer, step)
+
+
 @pytest.mark.parametrize("kind,ell,nq", [("hybrid", 10, 7), ("mixed", 9, 4)])
 def test_gen_eq_before_set_table_gives_the_same_step(kind, ell, nq, gpu_lib, monkeypatch):
     """The results do not depend on the order of the calls (include/reef_msm.h 3b): gen_eq_table FIRST, then a structured table --
