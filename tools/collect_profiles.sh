@@ -54,3 +54,4 @@ python $root/tools/time_stateless.py --threads 1,4,8 > $out/${R}_stateless_concu
 python $root/tools/time_concurrent_ipa.py > $out/${R}_concurrent_ipa.txt 2>&1
 python $root/tools/time_poseidon_latency.py > $out/${R}_poseidon_latency_raw.txt 2>&1
 for m in fresh contexts-alive threads-leftover torch-first; do python $root/tools/diag_queues2.py $m 2>&1 | grep -v amdgpu.ids; done > $out/${R}_concurrency_after.txt
+(python $root/tools/step_breakdown.py 26; python $root/tools/step_breakdown.py 21; echo "# REEF_SC_DEFER=0 (the first fold written out at once, round 3 form):"; REEF_SC_DEFER=0 python $root/tools/step_breakdown.py 26) > $out/${R}_step_breakdown.txt 2>&1
