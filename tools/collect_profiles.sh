@@ -55,3 +55,9 @@ python $root/tools/time_concurrent_ipa.py > $out/${R}_concurrent_ipa.txt 2>&1
 python $root/tools/time_poseidon_latency.py > $out/${R}_poseidon_latency_raw.txt 2>&1
 for m in fresh contexts-alive threads-leftover torch-first; do python $root/tools/diag_queues2.py $m 2>&1 | grep -v amdgpu.ids; done > $out/${R}_concurrency_after.txt
 (python $root/tools/step_breakdown.py 26; python $root/tools/step_breakdown.py 21; echo "# REEF_SC_DEFER=0 (the first fold written out at once, round 3 form):"; REEF_SC_DEFER=0 python $root/tools/step_breakdown.py 26) > $out/${R}_step_breakdown.txt 2>&1
+(echo "# tools/time_fold.py: four waves per group operation (shipped up to 2^14 outputs)"; python $root/tools/time_fold.py 8 12 14 15; echo "# REEF_MSM_FOLD_COOP=0: one wave"; REEF_MSM_FOLD_COOP=0 python $root/tools/time_fold.py 8 12 14 15) > $out/${R}_fold_timing.txt 2>&1
+(echo "# python tools/step_breakdown.py, the small rounds of a step: shipped"; python $root/tools/step_breakdown.py 21; python $root/tools/step_breakdown.py 26
+ echo "# REEF_SC_SPLIT_MAX=0: every dense round with a thread per item (an item's four folds, three products and three reductions one after the other)"; REEF_SC_SPLIT_MAX=0 python $root/tools/step_breakdown.py 21
+ echo "# REEF_SC_SPLIT_MAX=0 REEF_SC_ITEMS=1 REEF_SC_FLOOR=1: and a pair per thread in the mid-sized rounds (the round 3 grid)"; REEF_SC_SPLIT_MAX=0 REEF_SC_ITEMS=1 REEF_SC_FLOOR=1 python $root/tools/step_breakdown.py 21) > $out/${R}_small_rounds_ab.txt 2>&1
+(cd /tmp; for L in 21 26; do rm -rf /tmp/tl$L; rocprofv3 --kernel-trace --output-format csv -d /tmp/tl$L -- python $root/tools/step_breakdown.py $L > /dev/null 2>&1; echo "## ell = $L: kernels of the last step (us)"; python $root/tools/step_timeline.py /tmp/tl$L/*/*kernel_trace.csv; done) > $out/${R}_step_timeline.txt 2>&1
+(export CHUNKS=0,5,8,10,16; python $root/tools/sweep_chunk.py 15 13; python $root/tools/sweep_chunk.py 16 15) > $out/${R}_chunk_sweep.txt 2>&1

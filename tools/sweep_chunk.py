@@ -11,7 +11,7 @@ if __name__ == "__main__":
     logn = int(sys.argv[1])
     cs = [int(x) for x in sys.argv[2:]] or [13, 15]
     for c in cs:
-        for chunk in (0, 8, 16, 32, 64, 128):
+        for chunk in [int(x) for x in os.environ.get("CHUNKS", "0,8,16,32,64,128").split(",")]:
             r = run(logn, c, 1, chunk=chunk)
             if r:
                 print(f"logn={logn} c={c} chunk={chunk:3d} total_ms={r[0]:.3f} accum_ms={r[1]:.3f}", flush=True)
