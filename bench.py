@@ -1,10 +1,11 @@
 #!/usr/bin/env python3
 """bench.py -- MSM scalar-point pairs/s of the MI355X backend (BASELINE.json metric).
 
-A step = one pass of the hot path over one batch of synthetic input: a batch of 32 MSMs of 2^20 Pallas points each
+A step = one pass of the hot path over one batch of synthetic input: a batch of 256 MSMs of 2^20 Pallas points each
 (BASELINE.json configs[1]; --msms-per-step) with the key and the scalars already resident in HBM, issued one by one over
-three streams.  (Rounds 1-2 counted ONE MSM as a step: 20 steps were 26 ms, too short for an external sampler to see the GPU
-busy; `config.ms_per_msm` is the figure those rounds called ms_per_step.)
+three streams.  (Rounds 1-2 counted ONE MSM as a step, round 3 a batch of 32: the driver's 20 steps were 26 ms, then 0.8 s of a
+13 s run, and its sampler never saw the GPU busy; with 256 they are ~6 s.  `config.ms_per_msm` is the figure rounds 1-2 called
+ms_per_step; `value` -- pairs per second -- does not depend on the batch.)
     python bench.py --gpus N --steps K --warmup W
 For N > 1 the driver launches one rank per GPU with torch.distributed.run; every rank owns its
 own 2^20 points of one N*2^20-point MSM (weak scaling), the 96-byte partial sums are exchanged
@@ -39,10 +40,11 @@ FMUL_PEAK = 1.57e11            # Montgomery products/s chip-wide, measured (reef
 def parse():
     p = argparse.ArgumentParser()
     p.add_argument("--gpus", type=int, default=1)
-    p.add_argument("--steps", type=int, default=40, help="timed steps; a step is one batch of --msms-per-step MSMs (40 x 32 x 1.25 ms = 1.6 s: long enough "
-                                                        "for an external sampler to see the GPU busy)")
-    p.add_argument("--msms-per-step", type=int, default=32, help="MSMs of 2^logn points per step, issued one by one over the streams (the batch of synthetic "
-                                                                 "input one step passes through the hot path)")
+    p.add_argument("--steps", type=int, default=20, help="timed steps; a step is one batch of --msms-per-step MSMs")
+    p.add_argument("--msms-per-step", type=int, default=256, help="MSMs of 2^logn points per step, issued one by one over the streams (the batch of synthetic "
+                                                                  "input one step passes through the hot path).  256 x 1.2 ms = 0.3 s a step, so that the driver's "
+                                                                  "20 steps are a timed region of ~6 s: long enough for an external sampler at 5 s intervals to see "
+                                                                  "the GPU busy (rounds 1-3: 0 of 3 samples)")
     p.add_argument("--warmup", type=int, default=5)
     p.add_argument("--logn", type=int, default=20, help="log2 of points per GPU (BASELINE configs[1]: 20)")
     p.add_argument("--curve", default="pallas")

@@ -57,8 +57,8 @@ def test_bench_with_two_ranks(sharding, logn, gpu_lib):
         fs, scs = ss["final_snark"], ss["sumcheck"]            # round 4: whole units over the ranks
         assert fs["owner"] == [0, 1, 1] and fs["check"] == "same-points" and fs["ms"] > 0 and fs["one_gpu_one_after_the_other_ms"] > 0
         assert scs["ell"] == 26 and scs["entries_per_rank"] == 1 << 25 and scs["check"] == "sumcheck-identity-ok" and scs["ms_per_step"] > 0
-        assert set(ss["speedup_vs_1"]) == {"windows", "points"} and ss["one_gpu_ms_per_msm"] == pytest.approx(cfg["ms_per_msm"]) and cfg["msms_per_step"] == 32 \
-            and line["ms_per_step"] == pytest.approx(32 * cfg["ms_per_msm"])
+        assert set(ss["speedup_vs_1"]) == {"windows", "points"} and ss["one_gpu_ms_per_msm"] == pytest.approx(cfg["ms_per_msm"]) and cfg["msms_per_step"] == 256 \
+            and line["ms_per_step"] == pytest.approx(256 * cfg["ms_per_msm"])
     else:
         assert line["scaling"] == "strong" and cfg["total_points"] == 1 << logn and cfg["sharding"].startswith("windows")
         assert cfg["strong_scaling"] is None

@@ -2,9 +2,9 @@
 # On the MI355X box: everything profiles/ holds for a round.  usage: tools/collect_profiles.sh OUTDIR [rNN]
 out=$(realpath -m $1); R=${2:-r04}; export REEF_ROUND=$R
 mkdir -p $out; export TMPDIR=/tmp; root=$GRAFT_REPO_ROOT
-python $root/bench.py > $out/${R}_bench.json 2> $out/${R}_bench.err
+python $root/bench.py --steps 20 --warmup 5 > $out/${R}_bench.json 2> $out/${R}_bench.err
 # per-kernel time of the same timed region: the legs that run other sizes through the same kernels after it (replay, CPU) are left out
-(cd /tmp && rm -rf /tmp/ks && rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/ks -- python $root/bench.py --no-cpu-baseline --no-replay > $out/${R}_bench_under_rocprof.json 2>/dev/null; cp /tmp/ks/*/*kernel_stats.csv $out/${R}_kernel_stats.csv)
+(cd /tmp && rm -rf /tmp/ks && rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/ks -- python $root/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-replay > $out/${R}_bench_under_rocprof.json 2>/dev/null; cp /tmp/ks/*/*kernel_stats.csv $out/${R}_kernel_stats.csv)
 python $root/tools/pmc_traffic.py $out > $out/${R}_pmc_traffic.log 2>&1
 python $root/tools/pmc_valu.py $out/${R}_pmc_valu_issue.json > /dev/null 2>&1
 python $root/tools/sweep_plans.py 12 14 15 16 17 18 20 2>&1 | grep "##" > $out/${R}_latency_sweep.txt
