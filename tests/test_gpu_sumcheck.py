@@ -170,6 +170,45 @@ def test_fused_fold_and_next_coeffs(gpu_lib):
         assert sc.read(0, 1) == [t[0]] and sc.read(1, 1) == [e[0]]
 
 
+@pytest.mark.parametrize("curve,ell,env", [
+    ("pallas", 12, {}),                                                              # shipped grids: split rounds of 1 .. 32 workgroups
+    ("vesta", 11, {"REEF_SC_SPLIT_BLOCKS": "1"}),                                    # one workgroup walks all the items (16 passes at 2^10 pairs of pairs)
+    ("pallas", 12, {"REEF_SC_SPLIT_BLOCKS": "3"}),                                   # workgroups with unequal numbers of passes, the last one ragged
+    ("pallas", 12, {"REEF_SC_SPLIT_MAX": "0", "REEF_SC_ITEMS": "8", "REEF_SC_FLOOR": "2"}),   # no split; long threads down to two workgroups
+    ("pallas", 12, {"REEF_SC_SPLIT_MAX": "64", "REEF_SC_ITEMS": "3", "REEF_SC_FLOOR": "1", "REEF_SC_BLOCKS": "5"}),   # grid-stride tails in the dense kernels
+    ("pallas", 13, {"REEF_SC_ONE_LAUNCH": "0"}),                                     # every round through the second kernel (the split form is a one-launch form: off)
+])
+def test_small_and_mid_round_grids(curve, ell, env, gpu_lib, monkeypatch):
+    """The round-4 grids of the dense rounds -- an item's four folds and three products on the four waves of a workgroup
+    (k_sc_fold_coeffs_split), several pairs per thread in the mid-sized rounds, the wave sums through DPP, limb sums folded back by
+    fe_from_limb_sums -- against the oracle round by round, with the edge challenges 0, 1 and q - 1 among the random ones and a
+    second step on the same context."""
+    from reef_amd.sumcheck import SumCheck
+    from oracle.pasta_oracle import CURVES
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    q = CURVES[curve].order
+    rng = SplitMix64(ell * 31 + len(env))
+    n = 1 << ell
+    with SumCheck(curve, ell) as sc:
+        for step in range(2):
+            t = [uniform_scalar(rng, q) for _ in range(n)]
+            e = [uniform_scalar(rng, q) for _ in range(n)]
+            t[3], t[n - 1], e[0], e[5] = 0, q - 1, q - 1, 0
+            sc.set_table(0, t)
+            sc.set_table(1, e)
+            g = sc.round_coeffs(1)
+            for i in range(1, ell + 1):
+                assert g == linear_mle_coeffs(t, e, ell, i, q), (step, i)
+                r = {3: 0, 5: 1, 7: q - 1}.get(i, uniform_scalar(rng, q))
+                linear_mle_fold(t, e, ell, i, r, q)
+                if i < ell:
+                    g = sc.fold_and_next_coeffs(i, r)
+                else:
+                    sc.fold(i, r)
+            assert sc.read(0, 1) == [t[0]] and sc.read(1, 1) == [e[0]]
+
+
 @pytest.mark.parametrize("curve,ell,n_t,nq,fused", [("pallas", 2, 3, 1, False), ("pallas", 3, 8, 3, True), ("pallas", 7, 100, 9, True),
                                                      ("pallas", 11, 2000, 40, True), ("pallas", 12, 1 << 12, 33, False),
                                                      ("vesta", 9, 300, 5, True), ("pallas", 10, 1 << 10, 0, True)])
