@@ -21,6 +21,9 @@
  * (it owns one HIP stream and one workspace); use one ctx (or clone) per concurrent caller.
  *
  * ABI changelog (reef_abi_version()):
+ *   5  round 5: device groups (reef_msm_group_*: one MSM split by window or by points, or the rows of a Hyrax commitment dealt out
+ *      whole, over several GPUs of ONE process, the partial sums exchanged inside the library); reef_runtime_opts.hw_queues is
+ *      the only way the library touches GPU_MAX_HW_QUEUES unless REEF_MSM_HW_QUEUES is exported (the load-time default is gone).
  *   4  round 4: reef_runtime_init / reef_abi_version / reef_msm_ctx_attach / reef_msm_multi / reef_key_cache_info added; the drop-in symbols' key cache is one table per process
  *      (clones per calling thread) instead of one cache per thread.
  *   3  round 3: reef_msm_opts.byte_tables = 0 changed meaning from "build the byte tables in the background" to "follow the
@@ -31,7 +34,7 @@
  */
 #ifndef REEF_MSM_H
 #define REEF_MSM_H
-#define REEF_ABI_VERSION 4
+#define REEF_ABI_VERSION 5
 
 #include <stdbool.h>
 #include <stddef.h>
@@ -427,6 +430,72 @@ reef_status reef_test_ec_op(int curve, int op, const reef_affine *p, const reef_
                             reef_jacobian *out, size_t n);
 /* Field-multiplication throughput probe: returns Montgomery products per second. */
 reef_status reef_bench_fmul(int field, uint32_t iters, double *products_per_s);
+
+/* ---------------------------------------------------------------------------------------------
+ * (5) Device groups: the multi-GPU split behind the C ABI, in ONE process.
+ *
+ * Reef's prover is one Rust process (src/backend/main.rs:82; src/backend/framework.rs:81-166: two OS threads, no process
+ * boundary), so what BASELINE's north_star asks for -- "large MSMs are split by Pippenger window across the 8 GPUs of one node
+ * with a reduce of the partial sums over xGMI" -- has to be reachable from one address space: a group owns one resident-key
+ * context per member device, issues a call on every member before it waits for any (one host thread per member: eight PCIe links
+ * carry the scalars at once), brings the 96-byte partial sums together on member 0's device and adds them there.
+ *
+ *   REEF_SPLIT_WINDOWS  every member holds the WHOLE key (members that share a device share one copy) and receives all the
+ *                       scalars; member i accumulates the Pippenger windows w = i (mod ndev) (reef_msm_ctx_set_window_split):
+ *                       the split north_star names.  The rows of reef_msm_group_rows are dealt out whole on such a group.
+ *   REEF_SPLIT_POINTS   member i holds points [i*n/ndev, (i+1)*n/ndev) of the key and receives that slice of every scalar
+ *                       vector: 1/ndev of the key memory and of the upload per device (SURVEY.md 8e.2 "by points").
+ *
+ * Exchange (reef_msm_group_info.exchange): REEF_EXCHANGE_PEER -- a member on another device than member 0 sends its partial sum
+ * with hipMemcpyPeerAsync on its own stream (xGMI between the GPUs of one node; peer access is enabled where the devices allow
+ * it), a member on member 0's device writes it in place; member 0's stream waits for the members' events and runs the sum
+ * kernel (RCCL has no elliptic-curve reduction and the payload is 96 bytes per member: latency, not bandwidth).
+ * REEF_EXCHANGE_HOST -- the labelled fallback: every member's last kernel stores into its slot of host-mapped pinned memory,
+ * the host waits for all members and the slots are summed on member 0's device.  gopts->exchange = 0 takes PEER.
+ *
+ * devices[] may REPEAT an ordinal: a group of 2 / 3 / 8 members on device 0 runs every code path on a one-GPU box (that is how
+ * tests/test_gpu_group.py covers it); members that share a device share the resident key (clones).  Results are identical to
+ * reef_msm / reef_msm_rows on one context, whatever the split.  A group serialises the calls made on it.
+ * Replaces, as (2) does on one device: nova-snark's CommitmentGens<G> + CE::commit [R] at src/backend/framework.rs:668-721 and
+ * HyraxPC::commit at src/backend/commitment.rs:187.
+ * ------------------------------------------------------------------------------------------- */
+typedef struct reef_msm_group reef_msm_group;
+enum { REEF_SPLIT_WINDOWS = 0, REEF_SPLIT_POINTS = 1 };
+enum { REEF_EXCHANGE_DEFAULT = 0, REEF_EXCHANGE_PEER = 1, REEF_EXCHANGE_HOST = 2 };
+typedef struct {
+    uint32_t split;        /* REEF_SPLIT_* */
+    uint32_t exchange;     /* REEF_EXCHANGE_* */
+    uint32_t reserved[6];
+} reef_msm_group_opts;
+typedef struct {
+    uint32_t members;          /* ndev */
+    uint32_t distinct_devices; /* how many different ordinals devices[] named */
+    uint32_t split, exchange;  /* as resolved */
+    uint32_t peer_members;     /* members on another device than member 0 whose device has direct peer access to it (xGMI) */
+    uint32_t reserved[3];
+    uint64_t key_points[16];   /* points of the key resident on each of the first 16 members */
+} reef_msm_group_info;
+/* bases: the whole key, n points, on the host or on devices[0] (bases_loc).  key_opts as for reef_msm_ctx_create (its `device`
+ * field is ignored: devices[] decides); 1 <= ndev <= 64. */
+reef_status reef_msm_group_create(reef_msm_group **out, int curve, const reef_affine *bases, size_t n, int bases_loc,
+                                  const reef_msm_opts *key_opts /* may be NULL */, const int *devices, size_t ndev,
+                                  const reef_msm_group_opts *gopts /* may be NULL: windows, peer */);
+void reef_msm_group_destroy(reef_msm_group *grp);
+reef_status reef_msm_group_info_get(reef_msm_group *grp, reef_msm_group_info *info);
+/* K1 over the group: out (HOST) = sum_{i<n} scalars[i] * key[i], n <= key length.  scalars: host memory, or device memory of
+ * devices[0] (the other devices fetch their share with peer copies). */
+reef_status reef_msm_group_msm(reef_msm_group *grp, const reef_fe *scalars, size_t n, int scalars_loc, bool is_mont, reef_jacobian *out);
+/* K2 over the group (REEF_SPLIT_WINDOWS groups: every member needs the first row_len points): reef_msm_rows with the rows dealt
+ * out in contiguous blocks, member i computing rows [i*rows/ndev, (i+1)*rows/ndev) whole and writing them straight into out
+ * (HOST): independent units, no exchange.  rows == 1 -- CE::commit with a blind -- is split by window like
+ * reef_msm_group_msm, the blind term added by member 0 only.  Arguments as reef_msm_rows; scalars / blinds / h on the host or on
+ * devices[0]. */
+reef_status reef_msm_group_rows(reef_msm_group *grp, const reef_fe *scalars, size_t rows, size_t row_len, int scalars_loc, bool is_mont,
+                                uint32_t max_scalar_bits, const reef_fe *blinds, const reef_affine *h, reef_jacobian *out);
+/* The same from one-byte document symbols (reef_msm_rows_symbols). */
+reef_status reef_msm_group_rows_symbols(reef_msm_group *grp, const uint8_t *symbols, size_t rows, size_t row_len, int symbols_loc,
+                                        uint32_t symbol_bits, const reef_fe *blinds, const reef_affine *h, bool blinds_are_mont,
+                                        reef_jacobian *out);
 
 #ifdef __cplusplus
 }

@@ -43,11 +43,20 @@ class RuntimeInfo(ctypes.Structure):
     _fields_ = [("hw_queues_env", c_int32), ("hw_queues_set_by_library", c_int32), ("abi_version", c_uint32), ("reserved", c_uint32)]
 
 
+class GroupOpts(ctypes.Structure):
+    _fields_ = [("split", c_uint32), ("exchange", c_uint32), ("reserved", c_uint32 * 6)]
+
+
+class GroupInfo(ctypes.Structure):
+    _fields_ = [("members", c_uint32), ("distinct_devices", c_uint32), ("split", c_uint32), ("exchange", c_uint32), ("peer_members", c_uint32),
+                ("reserved", c_uint32 * 3), ("key_points", c_uint64 * 16)]
+
+
 class KeyCacheStats(ctypes.Structure):
     _fields_ = [(n, c_uint64) for n in ("entries", "resident_keys", "resident_bytes", "builds", "hits", "clones", "misspeculated", "reserved")]
 
 
-ABI_VERSION = 4     # REEF_ABI_VERSION of include/reef_msm.h this binding was written against
+ABI_VERSION = 5     # REEF_ABI_VERSION of include/reef_msm.h this binding was written against
 
 
 def build(force: bool = False, jobs: int = 3) -> str:
@@ -115,6 +124,12 @@ def load() -> ctypes.CDLL:
         "reef_msm_ctx_byte_tables": (c_int, [vp]),
         "reef_msm_plan_for": (c_int, [c_size_t, c_uint32, c_uint32, POINTER(c_uint32), POINTER(c_uint32), POINTER(c_uint32),
                                       POINTER(c_uint32)]),
+        "reef_msm_group_create": (c_int, [POINTER(vp), c_int, vp, c_size_t, c_int, POINTER(MsmOpts), POINTER(c_int), c_size_t, POINTER(GroupOpts)]),
+        "reef_msm_group_destroy": (None, [vp]),
+        "reef_msm_group_info_get": (c_int, [vp, POINTER(GroupInfo)]),
+        "reef_msm_group_msm": (c_int, [vp, vp, c_size_t, c_int, c_bool, vp]),
+        "reef_msm_group_rows": (c_int, [vp, vp, c_size_t, c_size_t, c_int, c_bool, c_uint32, vp, vp, vp]),
+        "reef_msm_group_rows_symbols": (c_int, [vp, vp, c_size_t, c_size_t, c_int, c_uint32, vp, vp, c_bool, vp]),
         "reef_msm_folded": (c_int, [vp, vp, c_size_t, c_size_t, c_int, c_bool, vp, vp, c_size_t, vp, c_int]),
         "reef_sc_create": (c_int, [POINTER(vp), c_int, c_size_t]),
         "reef_sc_destroy": (None, [vp]),

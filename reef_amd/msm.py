@@ -273,6 +273,95 @@ class MsmContext:
         return out
 
 
+SPLIT_WINDOWS, SPLIT_POINTS = 0, 1
+EXCHANGE_PEER, EXCHANGE_HOST = 1, 2
+
+
+class MsmGroup:
+    """A commitment key resident on several GPUs of THIS process (reef_msm_group_*, include/reef_msm.h section 5): one MSM split by
+    Pippenger window (every device holds the key) or by points (every device holds a slice), the 96-byte partial sums exchanged
+    inside the library; on a windows group the rows of a Hyrax commitment are dealt out whole.  `devices` may repeat an ordinal."""
+
+    def __init__(self, curve, bases: Buf, devices, n: Optional[int] = None, *, split: int = SPLIT_WINDOWS, exchange: int = 0,
+                 window_bits: int = 0, bucket_groups: int = 1, chunk: int = 0, byte_tables: int = 0):
+        self.curve = curve_id(curve)
+        self._lib = _ffi.load()
+        if n is None:
+            if not isinstance(bases, np.ndarray):
+                raise ValueError("n is required for device-resident bases")
+            n = bases.shape[0]
+        loc, ptr = _loc_ptr(bases, 64 * n)
+        opts = MsmOpts(window_bits, bucket_groups, chunk, byte_tables, -1, (ctypes.c_uint32 * 3)(0, 0, 0))
+        gopts = _ffi.GroupOpts(split, exchange, (ctypes.c_uint32 * 6)(*([0] * 6)))
+        devs = (ctypes.c_int * len(devices))(*devices)
+        h = ctypes.c_void_p()
+        check(self._lib.reef_msm_group_create(ctypes.byref(h), self.curve, ptr, n, loc, ctypes.byref(opts), devs, len(devices), ctypes.byref(gopts)))
+        self._h = h
+        self.n = n
+
+    def info(self) -> dict:
+        gi = _ffi.GroupInfo()
+        check(self._lib.reef_msm_group_info_get(self._h, ctypes.byref(gi)))
+        return {"members": gi.members, "distinct_devices": gi.distinct_devices, "split": ("windows", "points")[gi.split],
+                "exchange": {1: "peer", 2: "host-staged"}[gi.exchange], "peer_members": gi.peer_members,
+                "key_points": list(gi.key_points[:min(gi.members, 16)])}
+
+    def msm(self, scalars: Buf, n: Optional[int] = None, *, is_mont: bool = True) -> np.ndarray:
+        if n is None:
+            if not isinstance(scalars, np.ndarray):
+                raise ValueError("n is required for device-resident scalars")
+            n = scalars.shape[0]
+        loc, ptr = _loc_ptr(scalars, 32 * n)
+        out = np.zeros(12, dtype=np.uint64)
+        check(self._lib.reef_msm_group_msm(self._h, ptr, n, loc, bool(is_mont), out.ctypes.data))
+        return out
+
+    def msm_rows(self, scalars: Buf, rows: int, row_len: int, *, is_mont: bool = True, max_scalar_bits: int = 0,
+                 blinds: Optional[Buf] = None, h: Optional[Buf] = None) -> np.ndarray:
+        loc, ptr = _loc_ptr(scalars, 32 * rows * row_len)
+        bptr = hptr = None
+        if blinds is not None:
+            bloc, bptr = _loc_ptr(blinds, 32 * rows)
+            hloc, hptr = _loc_ptr(h, 64)
+            if bloc != loc or hloc != loc:
+                raise ValueError("blinds and h must live where the scalars live")
+        out = np.zeros((rows, 12), dtype=np.uint64)
+        check(self._lib.reef_msm_group_rows(self._h, ptr, rows, row_len, loc, bool(is_mont), max_scalar_bits, bptr, hptr, out.ctypes.data))
+        return out
+
+    def msm_rows_symbols(self, symbols: Buf, rows: int, row_len: int, symbol_bits: int, *, blinds: Optional[Buf] = None,
+                         h: Optional[Buf] = None, blinds_are_mont: bool = True) -> np.ndarray:
+        if isinstance(symbols, np.ndarray) and symbols.dtype != np.uint8:
+            raise TypeError("symbols must be uint8")
+        loc, ptr = _loc_ptr(symbols, rows * row_len)
+        bptr = hptr = None
+        if blinds is not None:
+            bloc, bptr = _loc_ptr(blinds, 32 * rows)
+            hloc, hptr = _loc_ptr(h, 64)
+            if bloc != loc or hloc != loc:
+                raise ValueError("blinds and h must live where the symbols live")
+        out = np.zeros((rows, 12), dtype=np.uint64)
+        check(self._lib.reef_msm_group_rows_symbols(self._h, ptr, rows, row_len, loc, symbol_bits, bptr, hptr, bool(blinds_are_mont), out.ctypes.data))
+        return out
+
+    def close(self) -> None:
+        if getattr(self, "_h", None):
+            self._lib.reef_msm_group_destroy(self._h)
+            self._h = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 def msm_multi(ctxs, scalars, is_mont: bool = True) -> np.ndarray:
     """Several MSMs at once (reef_msm_multi): ctxs[i].msm(scalars[i]) for distinct contexts, host scalars, all enqueued before any
     is waited for.  Returns the commitments as a (count, 12) array."""

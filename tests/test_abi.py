@@ -82,6 +82,32 @@ def test_every_default_plan_is_runnable_up_to_the_key_limit():
     assert msm.plan_for(1 << 24, window_bits=20, bucket_groups=1)["tables"] == 13
 
 
+def test_struct_sizes_of_the_group_api_and_its_argument_errors():
+    """reef_msm_group_create (include/reef_msm.h section 5) rejects bad arguments before it touches a device: pure host logic."""
+    import numpy as np
+    assert ctypes.sizeof(_ffi.GroupOpts) == 32 and ctypes.sizeof(_ffi.GroupInfo) == 32 + 128
+    lib = _ffi.load()
+    bases = np.zeros((4, 8), dtype=np.uint64)
+    h = ctypes.c_void_p()
+    devs = (ctypes.c_int * 2)(0, 0)
+
+    def create(curve=0, ptr=bases.ctypes.data, n=4, d=devs, nd=2, g=None):
+        return lib.reef_msm_group_create(ctypes.byref(h), curve, ptr, n, 0, None, d, nd, g)
+    assert create(curve=7) == 1 and b"curve" in lib.reef_last_error()
+    assert create(ptr=None) == 1
+    assert create(d=None) == 1
+    assert create(nd=0) == 1 and create(nd=65) == 1 and b"members" in lib.reef_last_error()
+    assert create(g=ctypes.byref(_ffi.GroupOpts(2, 0))) == 1 and b"split" in lib.reef_last_error()
+    assert create(g=ctypes.byref(_ffi.GroupOpts(0, 3))) == 1 and b"exchange" in lib.reef_last_error()
+    assert create(d=(ctypes.c_int * 2)(0, -1)) == 1
+    assert lib.reef_msm_group_create(None, 0, bases.ctypes.data, 4, 0, None, devs, 2, None) == 1
+    if lib.reef_device_count() == 0:
+        assert create() == 3 and h.value is None                    # REEF_ERR_NO_GPU: fails loudly, nothing is created
+    assert lib.reef_msm_group_msm(None, None, 0, 0, True, None) == 1
+    assert lib.reef_msm_group_info_get(None, None) == 1
+    lib.reef_msm_group_destroy(None)                                # a no-op
+
+
 def test_unknown_curve_rejected():
     with pytest.raises(ValueError):
         msm.curve_id("bls12")

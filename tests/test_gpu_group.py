@@ -1,0 +1,164 @@
+"""Device groups (include/reef_msm.h section 5): the multi-GPU split behind the C ABI, in one process -- what a Rust prover can call
+(Reef is ONE process: src/backend/main.rs:82, src/backend/framework.rs:81-166; the MSM call sites the group serves:
+framework.rs:668-721, src/backend/commitment.rs:187).  A test box has one GPU, so `devices[]` repeats ordinal 0 (the header allows
+it): every member, every exchange and every split runs; only the peer copies between DIFFERENT devices do not (members of one
+device write their partial sums in place).  Every result is compared with the C oracle (oracle/pasta_ref.c)."""
+import ctypes
+import threading
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+CURVE = {"pallas": 0, "vesta": 1}
+
+
+@pytest.fixture(scope="module")
+def key(cref):
+    out = {}
+    for cid in (0, 1):
+        n = 5003                                            # not divisible by 2, 3 or 8
+        bases = cref.gen_bases_ap(cid, 401 + cid, 7, n)
+        bases[n // 2] = 0                                   # an identity base
+        out[cid] = bases
+    return out
+
+
+@pytest.mark.parametrize("members", [1, 2, 3, 8])
+@pytest.mark.parametrize("split", ["windows", "points"])
+@pytest.mark.parametrize("name", ["pallas", "vesta"])
+def test_group_msm_equals_the_oracle(name, split, members, gpu_lib, cref, key):
+    """One MSM over a group of 1 / 2 / 3 / 8 members on device 0, both splits, both curves, both exchanges; host and device
+    scalars; prefixes of the key (n < key length, n smaller than the member count, n = 0); both scalar conventions."""
+    from reef_amd import msm
+    cid = CURVE[name]
+    bases = key[cid]
+    n = bases.shape[0]
+    sp = msm.SPLIT_WINDOWS if split == "windows" else msm.SPLIT_POINTS
+    sc = cref.gen_scalars(cid, 55 + members, n, kind=0)
+    sc_w = cref.gen_scalars(cid, 56, n, kind=1)
+    canon = cref.gen_scalars(cid, 55 + members, n, kind=0, mont=False)
+    want = cref.compress(cid, cref.msm_pippenger(cid, bases, sc, threads=4))
+    want_w = cref.compress(cid, cref.msm_pippenger(cid, bases, sc_w, threads=4))
+    for exchange in (msm.EXCHANGE_PEER, msm.EXCHANGE_HOST):
+        with msm.MsmGroup(cid, bases, [0] * members, split=sp, exchange=exchange) as g:
+            info = g.info()
+            assert info["members"] == members and info["distinct_devices"] == 1 and info["split"] == split
+            assert info["exchange"] == ("peer" if exchange == msm.EXCHANGE_PEER else "host-staged")
+            if split == "points":
+                assert sum(info["key_points"]) == n and max(info["key_points"]) - min(info["key_points"]) <= 1
+            else:
+                assert info["key_points"] == [n] + [0] * (members - 1)        # one resident copy per DEVICE
+            assert msm.compress(cid, g.msm(sc)) == want
+            assert msm.compress(cid, g.msm(sc_w)) == want_w
+            assert msm.compress(cid, g.msm(canon, is_mont=False)) == want
+            dsc = msm.DeviceBuffer.from_host(sc)
+            assert msm.compress(cid, g.msm(dsc, n)) == want
+            for m in (0, 1, members - 1 if members > 1 else 2, 700, n - 1):
+                exp = cref.compress(cid, cref.msm_pippenger(cid, bases[:m].copy(), sc[:m].copy(), threads=2)) if m else bytes(32)
+                assert msm.compress(cid, g.msm(sc[:m].copy() if m else np.zeros((0, 4), np.uint64), m)) == exp, (m, exchange)
+            assert msm.compress(cid, g.msm(sc)) == want                       # and whole again after the prefixes
+
+
+@pytest.mark.parametrize("groups", [0, 4])
+def test_group_on_keys_that_are_not_pre_shifted(groups, gpu_lib, cref, key):
+    """The group takes the key options of reef_msm_ctx_create: plain keys (a bucket group per window) and partial precompute."""
+    from reef_amd import msm
+    cid = 0
+    bases = key[cid]
+    sc = cref.gen_scalars(cid, 91, bases.shape[0], kind=0)
+    want = cref.compress(cid, cref.msm_pippenger(cid, bases, sc, threads=4))
+    for sp in (msm.SPLIT_WINDOWS, msm.SPLIT_POINTS):
+        with msm.MsmGroup(cid, bases, [0, 0, 0], split=sp, bucket_groups=groups) as g:
+            assert msm.compress(cid, g.msm(sc)) == want
+
+
+@pytest.mark.parametrize("members", [2, 3, 8])
+def test_group_rows_dealt_out_whole(members, gpu_lib, cref, key):
+    """HyraxPC::commit over a group (commitment.rs:187): rows in contiguous blocks, a row count that the member count does not
+    divide, fewer rows than members, blinds; full-width rows, symbol-sized rows as field elements and as bytes; rows == 1 with a
+    blind is split by window with the blind term on member 0 only."""
+    from reef_amd import msm
+    cid = 0
+    bases = key[cid]
+    h = cref.gen_bases_ap(cid, 0xB11D, 1, 1)[0].copy()
+    with msm.MsmGroup(cid, bases, [0] * members, split=msm.SPLIT_WINDOWS) as g:
+        for rows, row_len, bound in ((7, 600, 0), (members - 1, 900, 0), (37, 512, 7), (1300, 300, 131)):
+            kind = 2 if bound else 0
+            sc = cref.gen_scalars(cid, 4242 + rows, rows * row_len, kind=kind, small_bound=bound)
+            bl = cref.gen_scalars(cid, 8, rows)
+            kb = bases[:row_len].copy()
+            exp = cref.compress(cid, cref.row_msm(cid, kb, sc, rows, row_len, h=h, blinds=bl, threads=8))
+            exp_nb = cref.compress(cid, cref.row_msm(cid, kb, sc, rows, row_len, threads=8))
+            assert msm.compress(cid, g.msm_rows(sc, rows, row_len, blinds=bl, h=h)) == exp, (rows, row_len, bound)
+            assert msm.compress(cid, g.msm_rows(sc, rows, row_len)) == exp_nb
+            dsc, dbl, dh = msm.DeviceBuffer.from_host(sc), msm.DeviceBuffer.from_host(bl), msm.DeviceBuffer.from_host(h)
+            assert msm.compress(cid, g.msm_rows(dsc, rows, row_len, blinds=dbl, h=dh)) == exp
+            if bound:
+                canon = cref.gen_scalars(cid, 4242 + rows, rows * row_len, kind=2, small_bound=bound, mont=False)
+                sym = np.ascontiguousarray(canon[:, 0].astype(np.uint8))
+                bits = max(1, (bound - 1).bit_length())
+                assert msm.compress(cid, g.msm_rows_symbols(sym, rows, row_len, bits, blinds=bl, h=h)) == exp
+                assert msm.compress(cid, g.msm_rows_symbols(sym[:row_len].copy(), 1, row_len, bits, blinds=bl[:1].copy(), h=h)) == exp[:32]
+        # CE::commit with a blind: one row, split by window
+        n = bases.shape[0]
+        v = cref.gen_scalars(cid, 77, n)
+        b = cref.gen_scalars(cid, 78, 1)
+        exp1 = cref.compress(cid, cref.row_msm(cid, bases, v, 1, n, h=h, blinds=b, threads=4))
+        assert msm.compress(cid, g.msm_rows(v, 1, n, blinds=b, h=h)) == exp1
+        assert msm.compress(cid, g.msm_rows(v, 1, n)) == cref.compress(cid, cref.msm_pippenger(cid, bases, v, threads=4))
+        assert msm.compress(cid, g.msm(v)) == cref.compress(cid, cref.msm_pippenger(cid, bases, v, threads=4))     # the split ctx is untouched by rows
+    with msm.MsmGroup(cid, bases, [0, 0], split=msm.SPLIT_POINTS) as g:
+        with pytest.raises(msm.ReefError) as e:
+            g.msm_rows(cref.gen_scalars(cid, 1, 20), 2, 10)
+        assert e.value.status == 1 and "REEF_SPLIT_WINDOWS" in str(e.value)
+
+
+def test_group_at_the_headline_size_dlog_property(gpu_lib):
+    """configs[1]'s 2^20-point key over groups of 2 and 8 members: both splits against the discrete-log closed form (bases
+    B_i = (k0 + i d) G, so sum s_i B_i = (sum s_i (k0 + i d)) G) and against one context."""
+    from oracle.pasta_oracle import CURVES
+    from reef_amd import msm
+    cid, n, k0, d = 0, 1 << 20, 12345, 7
+    C = CURVES["pallas"]
+    dbases = msm.gen_bases(cid, k0, d, n, device=True)
+    sc = msm.gen_scalars(cid, 0x5EEF, n, kind=0, mont=False)
+    cols = [sc[:, j].astype(object) for j in range(4)]
+    idx = np.arange(n, dtype=object)
+    total = sum((int(np.sum(cols[j])) * k0 + int(np.sum(cols[j] * idx)) * d) << (64 * j) for j in range(4)) % C.order
+    want = C.compress(C.mul(total, C.gen))
+    for members, sp in ((2, msm.SPLIT_WINDOWS), (8, msm.SPLIT_WINDOWS), (8, msm.SPLIT_POINTS), (3, msm.SPLIT_POINTS)):
+        with msm.MsmGroup(cid, dbases, [0] * members, n, split=sp) as g:
+            assert msm.compress(cid, g.msm(sc, is_mont=False)) == want, (members, sp)
+
+
+def test_groups_from_several_threads_and_bad_arguments(gpu_lib, cref, key):
+    """A group serialises its calls; two groups work side by side; argument errors are REEF_ERR_ARG with a message."""
+    from reef_amd import _ffi, msm
+    cid = 0
+    bases = key[cid]
+    n = bases.shape[0]
+    scs = [cref.gen_scalars(cid, 300 + j, n, kind=j % 2) for j in range(4)]
+    want = [cref.compress(cid, cref.msm_pippenger(cid, bases, s, threads=4)) for s in scs]
+    errs = []
+    with msm.MsmGroup(cid, bases, [0, 0, 0], split=msm.SPLIT_WINDOWS) as ga, msm.MsmGroup(cid, bases, [0, 0], split=msm.SPLIT_POINTS) as gb:
+        def work(t):
+            try:
+                for rep in range(6):
+                    j = (t + rep) % 4
+                    g = ga if (t + rep) % 2 else gb
+                    assert msm.compress(cid, g.msm(scs[j])) == want[j], (t, rep)
+            except BaseException as e:
+                errs.append(repr(e))
+        ts = [threading.Thread(target=work, args=(t,)) for t in range(4)]
+        [t.start() for t in ts]
+        [t.join() for t in ts]
+        assert not errs, errs[:2]
+        with pytest.raises(msm.ReefError) as e:
+            ga.msm(np.zeros((n + 1, 4), np.uint64))
+        assert e.value.status == 1
+    lib = _ffi.load()
+    h = ctypes.c_void_p()
+    devs = (ctypes.c_int * 2)(0, lib.reef_device_count())                          # the second ordinal does not exist
+    assert lib.reef_msm_group_create(ctypes.byref(h), 0, bases.ctypes.data, n, 0, None, devs, 2, None) == 1
+    assert b"visible" in lib.reef_last_error()
