@@ -65,6 +65,9 @@ def parse():
     p.add_argument("--sharding", default="points", choices=["points", "windows"],
                    help="N > 1: 'points' = every GPU owns its own 2^logn pairs of one N*2^logn-point MSM (weak scaling, default); "
                         "'windows' = ONE 2^logn-point MSM, GPU r accumulates the Pippenger windows w = r mod N (strong scaling)")
+    p.add_argument("--single-process", action="store_true",
+                   help="with --gpus N and NO torchrun: ONE process drives N members through the library's device groups (reef_msm_group_*, "
+                        "include/reef_msm.h section 5) -- what a Rust prover can call; members beyond the visible devices repeat ordinals (labelled)")
     p.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                    help="nccl = RCCL over xGMI (default); gloo = host-staged gather (debug / boxes without RCCL), labelled as such")
     return p.parse_args()
@@ -375,8 +378,182 @@ def independent_units_legs(a, rank, world, dist):
     return out
 
 
+def single_process_main(a):
+    """`bench.py --gpus N --single-process`: the multi-GPU split as ONE process sees it -- no torch.distributed, no launcher: the C ABI's
+    device groups (reef_msm_group_*).  Reef's prover is one Rust process (src/backend/main.rs:82, framework.rs:81-166); this is the line
+    its integration would produce.  Timed region (`value`): weak scaling by points, as the torchrun path -- one N*2^logn-point MSM per
+    call over a points group (every member owns 2^logn pairs), three groups in flight from three caller threads, the scalars resident
+    on devices[0] (members on other devices fetch their slice over xGMI inside the call: labelled).  After it, the same strong_scaling
+    fields as the torchrun line: ONE 2^logn-point MSM split by window (north_star) and by points, and configs[3]'s Hyrax rows dealt
+    out whole; every combined point is checked against its discrete logarithm."""
+    import threading
+    import numpy as np
+    from reef_amd import msm
+    if os.environ.get("REEF_MSM_HW_QUEUES", "") != "0":
+        os.environ.setdefault("GPU_MAX_HW_QUEUES", os.environ.get("REEF_MSM_HW_QUEUES") or "8")
+    visible = msm.device_count()
+    if visible < 1:
+        raise SystemExit("bench.py --single-process: no HIP device visible (there is no CPU fallback)")
+    N = a.gpus
+    devices = [i % visible for i in range(N)]
+    n = 1 << a.logn
+    k0, d = 0xABCDEF, 0x12345
+    kind = 0 if a.scalars == "uniform" else 1
+    groups_opt = a.bucket_groups if a.bucket_groups >= 0 else 1
+    T = max(1, a.streams)
+    MPS = max(1, a.msms_per_step)
+    msm.set_device(devices[0])
+
+    def in_flight(calls, fns):
+        """`calls` calls dealt round-robin to len(fns) caller threads; -> seconds"""
+        per = [calls // len(fns) + (1 if j < calls % len(fns) else 0) for j in range(len(fns))]
+        errs = []
+
+        def work(j):
+            try:
+                for _ in range(per[j]):
+                    fns[j]()
+            except BaseException as e:
+                errs.append(repr(e))
+        th = [threading.Thread(target=work, args=(j,)) for j in range(len(fns))]
+        t0 = time.perf_counter()
+        [x.start() for x in th]
+        [x.join() for x in th]
+        dt = time.perf_counter() - t0
+        if errs:
+            raise RuntimeError(errs[0])
+        return dt
+
+    # ---- the timed region: weak scaling by points
+    bases_all = msm.gen_bases(a.curve, k0, d, N * n, device=True)
+    sc_all = msm.gen_scalars(a.curve, 0x5EEF, N * n, kind=kind, mont=True, device=True)
+    wg = [msm.MsmGroup(a.curve, bases_all, devices, N * n, split=msm.SPLIT_POINTS, window_bits=a.window_bits, bucket_groups=groups_opt, chunk=a.chunk)
+          for _ in range(T)]
+    info = wg[0].info()
+    last = [None] * T
+
+    def weak_call(j):
+        def f():
+            last[j] = wg[j].msm(sc_all, N * n)
+        return f
+    wf = [weak_call(j) for j in range(T)]
+    in_flight(max(T, a.warmup * MPS), wf)
+    elapsed = in_flight(a.steps * MPS, wf)
+    weak_ms = elapsed / (a.steps * MPS) * 1e3
+    # the same calls with the scalars in (pageable) HOST memory, as a Rust Vec is: every member uploads its own slice over its own link
+    hs_all = sc_all.to_host((N * n, 4))
+    hf = [(lambda j: (lambda: wg[j].msm(hs_all)))(j) for j in range(T)]
+    in_flight(T, hf)
+    hcalls = max(T, min(a.steps * MPS, 24))
+    host_ms = in_flight(hcalls, hf) / hcalls * 1e3
+    check_ok = True
+    if not a.no_check:
+        canon = msm.gen_scalars(a.curve, 0x5EEF, N * n, kind=kind, mont=False)
+        want_all = point_of_dlog(a.curve, dlog_of_msm(a.curve, canon, k0, d, 0))
+        check_ok = all(msm.compress(a.curve, r) == want_all for r in last if r is not None) and msm.compress(a.curve, wg[0].msm(hs_all)) == want_all
+    for g in wg:
+        g.close()
+
+    # ---- one GPU, the same protocol: what one member needs for a 2^logn-point MSM with T calls in flight
+    bases1 = msm.gen_bases(a.curve, k0, d, n, device=True)
+    sc1 = msm.gen_scalars(a.curve, 0x5EEF, n, kind=kind, mont=True, device=True)
+    c0 = msm.MsmContext(a.curve, bases1, n, window_bits=a.window_bits, bucket_groups=groups_opt, chunk=a.chunk, device=devices[0])
+    cs = [c0] + [c0.clone() for _ in range(T - 1)]
+    plan = c0.plan()
+    for c_ in cs:
+        c_.enable_timing(True)
+    outs = [np.zeros(12, dtype=np.uint64) for _ in cs]
+    of = [(lambda j: (lambda: cs[j].msm(sc1, n, out=outs[j])))(j) for j in range(T)]
+    in_flight(T, of)
+    for c_ in cs:
+        c_.timing_stats(reset=True)
+    ocalls = max(T, min(a.steps * MPS, 48))
+    one_gpu_ms = in_flight(ocalls, of) / ocalls * 1e3
+    st = [c_.timing_stats(reset=True) for c_ in cs]
+    acc_ms = sum(x["accumulate_ms"] for x in st) / max(1, sum(x["calls"] for x in st))
+    want1 = None
+    if not a.no_check:
+        canon1 = msm.gen_scalars(a.curve, 0x5EEF, n, kind=kind, mont=False)
+        want1 = point_of_dlog(a.curve, dlog_of_msm(a.curve, canon1, k0, d, 0))
+        check_ok = check_ok and msm.compress(a.curve, outs[0]) == want1
+    for c_ in cs:
+        c_.close()
+
+    # ---- strong scaling: ONE 2^logn-point MSM over the members, by window and by points; latency (one call in flight) and T in flight
+    strong = {"one_msm_points": n, "in_flight": T, "one_gpu_ms_per_msm": one_gpu_ms}
+    for name, sp in (("windows", msm.SPLIT_WINDOWS), ("points", msm.SPLIT_POINTS)):
+        gs = [msm.MsmGroup(a.curve, bases1, devices, n, split=sp, window_bits=a.window_bits, bucket_groups=groups_opt, chunk=a.chunk) for _ in range(T)]
+        res = [None] * T
+        gf = [(lambda j: (lambda: res.__setitem__(j, gs[j].msm(sc1, n))))(j) for j in range(T)]
+        in_flight(T, gf)
+        calls = max(T, min(a.steps * MPS, 24))
+        strong[name + "_ms_per_step"] = in_flight(calls, gf) / calls * 1e3
+        strong[name + "_latency_ms"] = in_flight(max(3, calls // T), gf[:1]) / max(3, calls // T) * 1e3
+        if want1 is not None:
+            check_ok = check_ok and all(msm.compress(a.curve, r) == want1 for r in res)
+        for g in gs:
+            g.close()
+    strong["speedup_vs_1"] = {"windows": one_gpu_ms / strong["windows_ms_per_step"], "points": one_gpu_ms / strong["points_ms_per_step"]}
+    strong["note"] = ("ONE 2^logn-point MSM over the members of a device group of THIS process: windows = member i accumulates the Pippenger windows "
+                      "w = i (mod N) on a replicated key (north_star's split), points = contiguous slices; *_ms_per_step with `in_flight` groups called from as "
+                      "many threads, *_latency_ms with one; one_gpu_ms_per_msm is one context per call on devices[0] under the same protocol")
+    # independent units: configs[3]'s Hyrax commitment, rows dealt out whole (document in host memory, as Reef holds it)
+    h_rows, h_len, h_bits, hk0, hd = 4096, 8192, 3, 0xFEED, 3
+    if a.logn >= 16:
+        doc = np.random.default_rng(0xD0C).integers(0, 7, size=(h_rows, h_len), dtype=np.uint8)
+        hb = msm.gen_bases(a.curve, hk0, hd, h_len, device=True)
+        with msm.MsmGroup(a.curve, hb, devices, h_len, split=msm.SPLIT_WINDOWS, bucket_groups=0) as hg:
+            flat = np.ascontiguousarray(doc.reshape(-1))
+            got = hg.msm_rows_symbols(flat, h_rows, h_len, h_bits)          # builds the symbol tables
+            reps = 3
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                got = hg.msm_rows_symbols(flat, h_rows, h_len, h_bits)
+            h_ms = (time.perf_counter() - t0) / reps * 1e3
+        from oracle.pasta_oracle import CURVES
+        order = CURVES[a.curve].order
+        rows_ok = True
+        for r_ in (0, h_rows // max(N, 1) - 1, h_rows // 2, h_rows - 1):
+            dl = sum(int(v) * (hk0 + j * hd) for j, v in enumerate(doc[r_].tolist())) % order
+            rows_ok = rows_ok and msm.compress(a.curve, got[r_].copy()) == point_of_dlog(a.curve, dl)
+        check_ok = check_ok and rows_ok
+        strong["hyrax_rows"] = {"rows": h_rows, "row_len": h_len, "symbol_bits": h_bits, "ms_per_commit": h_ms, "check": "dlog-ok" if rows_ok else "MISMATCH",
+                                "note": "HyraxPC::commit of a 16 MiB DNA document from host bytes, rows dealt out in contiguous blocks to the members, results written "
+                                        "straight into the caller's array (PCIe-inclusive)"}
+    value = N * n * a.steps * MPS / elapsed
+    achieved = BYTES_PER_PAIR * n / (acc_ms * 1e-3) / 1e9 if acc_ms > 0 else None
+    out = {"metric": "msm_scalar_point_pairs_per_sec", "value": value, "unit": "pairs/s", "n_gpus": N, "steps": a.steps, "warmup": a.warmup,
+           "ms_per_step": elapsed / a.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u32", "data": "synthetic",
+           "config": {"workload": f"one {N} x 2^{a.logn}-point {a.curve.capitalize()} MSM per call over a device group of {N} members (2^{a.logn} pairs per member), "
+                                  f"{a.scalars} 255-bit scalars; a step = {MPS} such calls, {T} groups in flight",
+                      "mode": "single-process: reef_msm_group_* of libreef_msm.so (no torch, no launcher) -- what a Rust prover calls",
+                      "devices": devices, "distinct_devices": info["distinct_devices"], "visible_devices": visible,
+                      "devices_note": None if info["distinct_devices"] == N else f"{N} members on {info['distinct_devices']} device(s): ordinals repeat, NOT a scaling measurement",
+                      "exchange": info["exchange"] + (" (hipMemcpyPeerAsync of the 96-byte partial sums to devices[0], sum kernel there; in place where members share a device)"
+                                                     if info["exchange"] == "peer" else ""),
+                      "peer_members": info["peer_members"], "key_points_per_member": info["key_points"],
+                      "scalars": "device-resident on devices[0]; members on other devices fetch their slice with a peer copy INSIDE the timed call",
+                      "ms_per_msm": weak_ms, "host_scalars_ms_per_msm": host_ms,
+                      "host_scalars_note": "the same calls with the scalars in pageable host memory (a Rust Vec): every member uploads its slice over its own PCIe link",
+                      "points_per_gpu": n, "total_points": N * n, "window_bits": plan["window_bits"], "windows": plan["windows"], "bucket_groups": plan["bucket_groups"],
+                      "tables": plan["tables"], "streams": T, "msms_per_step": MPS, "sharding": "points", "strong_scaling": strong,
+                      "check": ("dlog-ok" if check_ok else "MISMATCH") if not a.no_check else "skipped"},
+           "roofline": {"bound": "hbm", "kernel": "k_accum0 (bucket accumulation)", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": None, "kernel_ms": acc_ms,
+                        "algorithmic_bytes_per_launch": BYTES_PER_PAIR * n,
+                        "note": f"measured on the one-GPU leg of this run (HIP events on the contexts' streams, {T} MSMs in flight); the group's members run the same kernel"},
+           "cpu_baseline": None}
+    print(json.dumps(out), flush=True)
+    if not a.no_check and not check_ok:
+        sys.exit(2)
+
+
 def main():
     a = parse()
+    if a.single_process:
+        if int(os.environ.get("WORLD_SIZE", "1")) > 1:
+            raise SystemExit("bench.py --single-process runs WITHOUT torch.distributed.run: one process drives all the devices")
+        return single_process_main(a)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))

@@ -363,6 +363,7 @@ void reef_shake256(const uint8_t *in, size_t in_len, uint8_t *out, size_t out_le
  * ------------------------------------------------------------------------------------------- */
 int reef_device_count(void);
 reef_status reef_set_device(int ordinal);
+reef_status reef_get_device(int *ordinal);              /* the calling thread's current device */
 reef_status reef_device_sync(void);
 void *reef_device_alloc(size_t bytes);                 /* hipMalloc; NULL on failure */
 void reef_device_free(void *p);

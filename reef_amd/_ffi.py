@@ -105,6 +105,7 @@ def load() -> ctypes.CDLL:
         "reef_gen_scalars": (c_int, [c_int, c_uint64, c_int, c_uint64, c_size_t, c_bool, vp, c_int]),
         "reef_device_count": (c_int, []),
         "reef_set_device": (c_int, [c_int]),
+        "reef_get_device": (c_int, [POINTER(c_int)]),
         "reef_device_sync": (c_int, []),
         "reef_device_alloc": (vp, [c_size_t]),
         "reef_device_free": (None, [vp]),

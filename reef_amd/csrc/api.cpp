@@ -152,6 +152,11 @@ reef_status reef_set_device(int ordinal) {
     REEF_HIP_TRY(hipSetDevice(ordinal));
     return REEF_OK;
 }
+reef_status reef_get_device(int *ordinal) {
+    if (!ordinal) { set_error("null argument"); return REEF_ERR_ARG; }
+    REEF_HIP_TRY(hipGetDevice(ordinal));
+    return REEF_OK;
+}
 reef_status reef_device_sync(void) {
     REEF_HIP_TRY(hipDeviceSynchronize());
     return REEF_OK;

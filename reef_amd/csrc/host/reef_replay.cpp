@@ -13,6 +13,7 @@
 //   final SNARK      one more |C2| MSM, then for each curve an IPA over the padded key length:
 //                    log2 N rounds of { L, R cross MSMs (issued on two streams), generator fold }
 //   consistency      IPA of the Hyrax row length (prove_eval, commitment.rs:371/383)
+//   devices=N        the multi-device leg (replay_devices): arguments placed whole on N members, the document commitment through a device group
 // and, beside the MSMs: the Hyrax commitment of the document (--commit), one nlookup sum-check per
 // folding step (rows N2) and the document polynomial's row binding at proof end (row N3).
 //
@@ -33,6 +34,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <functional>
 #include <memory>
 #include <stdexcept>
 #include <string>
@@ -310,8 +312,137 @@ static double run_sumcheck_step(reef_sc_ctx *sc, int ell, int lookups) {
     return ms_since(t0);
 }
 
+
+// ---- the multi-device leg: what ONE prover process can hand to the other GPUs of its node (include/reef_msm.h section 5) ----
+// Reef's per-step MSMs are 2^14-2^16 points and are not split.  What a node can take from a --prove run is WHOLE units:
+//   * the final SNARK's three arguments (two Spartan IPAs, the consistency IPA; src/backend/framework.rs:695-721) on up to three
+//     devices, each argument's key and scalars resident on its device (reef_msm_opts.device), issued from three caller threads;
+//   * the Hyrax commitment of the document (src/backend/commitment.rs:187) through a device group (reef_msm_group_rows_symbols:
+//     rows dealt out whole, the document in host memory as Reef holds it), checked row for row against one device.
+// `ordinals` may repeat a device (a one-GPU box runs the whole leg on device 0; the JSON says how many devices were distinct).
+struct DeviceScope {
+    int prev = 0;
+    explicit DeviceScope(int dev) {
+        CK(reef_get_device(&prev));
+        CK(reef_set_device(dev));
+    }
+    ~DeviceScope() { (void)reef_set_device(prev); }
+};
+struct GroupFree { void operator()(reef_msm_group *p) const { if (p) reef_msm_group_destroy(p); } };
+static std::string replay_devices(const Shape &shape, const std::vector<int> &ordinals, bool tables) {
+    const Shape *sh = &shape;
+    const size_t nd = ordinals.size();
+    std::vector<int> uniq(ordinals);
+    std::sort(uniq.begin(), uniq.end());
+    uniq.erase(std::unique(uniq.begin(), uniq.end()), uniq.end());
+    struct Arg { const char *name; Curve c; int device; dev_ptr<reef_affine> gens; dev_ptr<reef_fe> sc; ctx_ptr key; double alone_ms = 0; };
+    std::vector<Arg> args(3);
+    args[0].name = "ipa_pallas"; args[0].c.id = REEF_PALLAS; args[0].c.n = next_pow2(std::max(sh->w1, sh->c1));
+    args[1].name = "ipa_vesta";  args[1].c.id = REEF_VESTA;  args[1].c.n = next_pow2(std::max(sh->w2, sh->c2));
+    args[2].name = "consistency"; args[2].c.id = REEF_PALLAS; args[2].c.n = sh->hyrax_row;
+    if (sh->hyrax_row < 2) args.pop_back();
+    // longest argument first onto the least loaded device (deterministic; the same rule as reef_amd/distributed.py::place_units)
+    std::vector<size_t> order(args.size());
+    for (size_t i = 0; i < order.size(); ++i) order[i] = i;
+    std::stable_sort(order.begin(), order.end(), [&](size_t a, size_t b) { return args[a].c.n > args[b].c.n; });
+    std::vector<double> load(nd, 0.0);
+    for (size_t k : order) {
+        size_t best = 0;
+        for (size_t d = 1; d < nd; ++d)
+            if (load[d] < load[best]) best = d;
+        args[k].device = ordinals[best];
+        load[best] += (double)args[k].c.n;
+    }
+    for (Arg &a : args) {
+        DeviceScope ds(a.device);
+        a.gens = device_alloc<reef_affine>(a.c.n);
+        CK(reef_gen_bases(a.c.id, 0xC0FFEE + a.c.id, 7, a.c.n, a.gens.get(), REEF_DEVICE));
+        a.sc = device_scalars(a.c.id, 12 + a.c.id, 0, a.c.n);
+        reef_msm_opts o = {};
+        o.bucket_groups = 1;
+        o.byte_tables = tables ? 1 : 2;
+        o.device = a.device;
+        CK(reef_msm_ctx_create(&a.c.key, a.c.id, a.gens.get(), a.c.n, REEF_DEVICE, &o));
+        a.key.reset(a.c.key);
+        run_ipa_nofold(a.c, a.c.n, a.sc.get(), nullptr);                     // warm-up: workspaces
+        a.alone_ms = run_ipa_nofold(a.c, a.c.n, a.sc.get(), nullptr);
+    }
+    double together_ms = 0;
+    {
+        std::vector<std::exception_ptr> err(args.size());
+        std::vector<std::thread> th;
+        auto tc = clk::now();
+        for (size_t k = 1; k < args.size(); ++k)
+            th.emplace_back([&, k] { try { run_ipa_nofold(args[k].c, args[k].c.n, args[k].sc.get(), nullptr); } catch (...) { err[k] = std::current_exception(); } });
+        try { run_ipa_nofold(args[0].c, args[0].c.n, args[0].sc.get(), nullptr); } catch (...) { err[0] = std::current_exception(); }
+        for (auto &t : th) t.join();
+        together_ms = ms_since(tc);
+        for (auto &e : err)
+            if (e) std::rethrow_exception(e);
+    }
+    // the document commitment over the group, against one device
+    double commit_group_ms = 0, commit_one_ms = 0;
+    reef_msm_group_info gi;
+    memset(&gi, 0, sizeof gi);
+    if (sh->doc_log) {
+        const size_t n_doc = (size_t)1 << sh->doc_log;
+        const size_t rows = (size_t)1 << (sh->doc_log / 2), row_len = (size_t)1 << (sh->doc_log - sh->doc_log / 2);
+        std::vector<uint8_t> doc(n_doc);
+        uint64_t x = 0xD0C;
+        const uint32_t bound = sh->symbol_bits >= 8 ? 131u : (sh->symbol_bits == 3 ? 7u : (1u << sh->symbol_bits));
+        for (size_t i = 0; i < n_doc; ++i) { x = x * 6364136223846793005ULL + 1442695040888963407ULL; doc[i] = (uint8_t)((x >> 33) % bound); }
+        std::vector<reef_affine> gens(row_len);
+        CK(reef_gen_bases(REEF_PALLAS, 0xFEED, 3, row_len, gens.data(), REEF_HOST));
+        reef_msm_group *grp = nullptr;
+        reef_msm_group_opts go = {};
+        go.split = REEF_SPLIT_WINDOWS;
+        CK(reef_msm_group_create(&grp, REEF_PALLAS, gens.data(), row_len, REEF_HOST, nullptr, ordinals.data(), nd, &go));
+        const std::unique_ptr<reef_msm_group, GroupFree> grp_owner(grp);
+        CK(reef_msm_group_info_get(grp, &gi));
+        std::vector<reef_jacobian> out_g(rows), out_1(rows);
+        CK(reef_msm_group_rows_symbols(grp, doc.data(), rows, row_len, REEF_HOST, (uint32_t)sh->symbol_bits, nullptr, nullptr, true, out_g.data()));   // builds the symbol tables
+        // the median of five: the first pageable copy a pool stream carries pays for the runtime's staging buffers (one-off, 5-20 ms),
+        // and the members take whichever stream is least busy
+        auto median5 = [&](const std::function<void()> &f) {
+            double t[5];
+            for (double &x : t) { auto t0 = clk::now(); f(); x = ms_since(t0); }
+            std::sort(t, t + 5);
+            return t[2];
+        };
+        commit_group_ms = median5([&] { CK(reef_msm_group_rows_symbols(grp, doc.data(), rows, row_len, REEF_HOST, (uint32_t)sh->symbol_bits, nullptr, nullptr, true, out_g.data())); });
+        reef_msm_ctx *one = nullptr;
+        reef_msm_opts o1 = {};
+        o1.device = ordinals[0];
+        CK(reef_msm_ctx_create(&one, REEF_PALLAS, gens.data(), row_len, REEF_HOST, &o1));
+        const ctx_ptr one_owner(one);
+        CK(reef_msm_rows_symbols(one, doc.data(), rows, row_len, REEF_HOST, (uint32_t)sh->symbol_bits, nullptr, nullptr, true, out_1.data(), REEF_HOST));
+        commit_one_ms = median5([&] { CK(reef_msm_rows_symbols(one, doc.data(), rows, row_len, REEF_HOST, (uint32_t)sh->symbol_bits, nullptr, nullptr, true, out_1.data(), REEF_HOST)); });
+        std::vector<reef_affine> ag(rows), a1(rows);
+        CK(reef_normalize(REEF_PALLAS, out_g.data(), rows, REEF_HOST, ag.data(), nullptr));
+        CK(reef_normalize(REEF_PALLAS, out_1.data(), rows, REEF_HOST, a1.data(), nullptr));
+        if (memcmp(ag.data(), a1.data(), rows * sizeof(reef_affine)) != 0) fail("reef_replay: the group's row commitments differ from one device's");
+    }
+    double sum_alone = 0, longest = 0;
+    for (Arg &a : args) { sum_alone += a.alone_ms; longest = std::max(longest, a.alone_ms); }
+    std::string placed = "[";
+    for (size_t k = 0; k < args.size(); ++k) {
+        char b[160];
+        snprintf(b, sizeof b, "%s{\"argument\": \"%s\", \"points\": %zu, \"device\": %d, \"alone_ms\": %.3f}", k ? ", " : "", args[k].name, args[k].c.n, args[k].device, args[k].alone_ms);
+        placed += b;
+    }
+    placed += "]";
+    std::vector<char> line(4096);
+    snprintf(line.data(), line.size(), "{\"members\": %zu, \"distinct_devices\": %zu, \"visible_devices\": %d, \"note\": \"one process: the final SNARK's arguments placed whole on the devices "
+             "(per-device contexts, one caller thread each), the document commitment through a device group; ordinals repeat when the box has fewer GPUs than members\", "
+             "\"final_snark_placed\": %s, \"three_arguments_one_after_the_other_ms\": %.3f, \"three_arguments_on_devices_ms\": %.3f, \"longest_argument_ms\": %.3f, "
+             "\"commit_hyrax_group_ms\": %.3f, \"commit_hyrax_one_device_ms\": %.3f, \"commit_rows_checked_against_one_device\": %s, \"group_exchange\": \"%s\", \"group_peer_members\": %u}",
+             nd, uniq.size(), reef_device_count(), placed.c_str(), sum_alone, together_ms, longest, commit_group_ms, commit_one_ms, sh->doc_log ? "true" : "false",
+             gi.exchange == REEF_EXCHANGE_HOST ? "host-staged" : "peer copies (hipMemcpyPeerAsync; in place on a shared device)", gi.peer_members);
+    return std::string(line.data());
+}
+
 // The whole replay of one config; returns the JSON line.
-static std::string replay_body(const Shape &shape, bool nofold, bool tables, const std::string &shapes_path) {
+static std::string replay_body(const Shape &shape, bool nofold, bool tables, const std::string &shapes_path, const std::vector<int> &ordinals) {
     const Shape *sh = &shape;
     Curve cv[2];
     cv[0].id = REEF_PALLAS; cv[0].n = next_pow2(sh->w1 > sh->c1 ? sh->w1 : sh->c1);
@@ -597,8 +728,9 @@ static std::string replay_body(const Shape &shape, bool nofold, bool tables, con
         merkle_ms = ms_since(t0);
     }
 
+    const std::string devices_json = ordinals.empty() ? std::string("null") : replay_devices(shape, ordinals, tables);
     const size_t pairs_step = sh->c2 + sh->w1 + sh->c1 + sh->w2;
-    std::vector<char> line(8192);
+    std::vector<char> line(16384);
     snprintf(line.data(), line.size(), "{\"replay\": \"%s\", \"ipa\": \"%s\", \"note\": \"MSM work of reef --prove replayed through the C ABI; host-side proving work not included\", "
            "\"shapes\": \"PREDICTED by Reef's cost model (src/backend/costs.rs restated in oracle/costs_oracle.py, read from %s), not measured on a Reef run\", \"w1\": %zu, \"c1\": %zu, \"w2\": %zu, \"c2\": %zu, "
            "\"scalars\": \"per-step vectors in host memory, commitments returned to the host (PCIe inclusive)\", \"commitments_checked_against_dlog\": %d, "
@@ -607,11 +739,11 @@ static std::string replay_body(const Shape &shape, bool nofold, bool tables, con
            "\"ipa_vesta_rounds\": %d, \"consistency_ipa_ms\": %.3f, \"consistency_rounds\": %d, \"three_arguments_concurrently_ms\": %.3f, \"total_prove_msm_ms\": %.3f, "
            "\"commit_hyrax_ms\": %.3f, \"commit_hyrax_first_call_ms\": %.3f, \"sumcheck_table_log\": %d, \"sumcheck_ms_per_step\": %.3f, "
            "\"doc_poly_bind_rows_ms\": %.3f, \"total_prove_gpu_ms\": %.3f, \"derive_both_keys_ms\": %.3f, \"commit_merkle_log\": %d, \"commit_merkle_ms\": %.3f, "
-           "\"standins\": \"key derivation and Poseidon run on stand-in parameter sets (replay_standins.h), timing only\", \"byte_tables\": %s}",
+           "\"standins\": \"key derivation and Poseidon run on stand-in parameter sets (replay_standins.h), timing only\", \"byte_tables\": %s, \"devices\": %s}",
            sh->name.c_str(), nofold ? "cross terms over the original key (no generator fold)" : "generator fold per round", shapes_path.c_str(), sh->w1, sh->c1, sh->w2, sh->c2, g_checked, cv[0].n, cv[1].n, sh->steps, setup_ms, steps_ms, steps_ms / sh->steps, steps_batched_ms / sh->steps, steps_conc_ms / sh->steps, steps_all4_ms / sh->steps, pairs_step, final_ms, ipa1_ms, r1, ipa2_ms, r2,
            cons_ms, r3, concurrent_ms, steps_ms + final_ms + cons_ms, commit_ms, commit_first_ms, sh->table_log, sc_step_ms, mle_ms,
            steps_ms + final_ms + cons_ms + sh->steps * sc_step_ms + mle_ms, derive_ms, sh->merkle_log, merkle_ms,
-           tables ? "\"built with the keys (inside setup_ms): MSMs of 1025..65536 points are sums of table entries\"" : "\"none (bucket pipeline)\"");
+           tables ? "\"built with the keys (inside setup_ms): MSMs of 1025..65536 points are sums of table entries\"" : "\"none (bucket pipeline)\"", devices_json.c_str());
     return std::string(line.data());        // the owners above release every context and device buffer, here or on an exception
 }
 
@@ -619,21 +751,33 @@ static std::string replay_body(const Shape &shape, bool nofold, bool tables, con
 // Runs the replay of the config whose name contains `config` ("cfg1" | "cfg3" | "cfg4" | "cfg5") with the shapes of
 // `shapes_json` (NULL: $REEF_REPLAY_SHAPES).  On success returns 0 and writes the JSON line (NUL-terminated) to out; on
 // failure returns non-zero and writes the message.  Every per-step commitment has been checked by then.
+// reef_replay_run_devices: the same, followed by the multi-device leg on `devices[0 .. ndev)` (ordinals may repeat; ndev = 0: none).
 extern "C" __attribute__((visibility("default")))
-int reef_replay_run(const char *shapes_json, const char *config, int nofold, int tables, char *out, size_t cap) {
+int reef_replay_run_devices(const char *shapes_json, const char *config, int nofold, int tables, const int *devices, size_t ndev, char *out, size_t cap) {
     auto put = [&](const std::string &m) { if (out && cap) { snprintf(out, cap, "%s", m.c_str()); } };
     try {
+        std::vector<int> ordinals;
+        if (ndev > 64 || (ndev && !devices)) fail("devices: 0..64 ordinals");
+        for (size_t i = 0; i < ndev; ++i) {
+            if (devices[i] < 0 || devices[i] >= reef_device_count()) fail("devices: ordinal " + std::to_string(devices[i]) + " is not visible");
+            ordinals.push_back(devices[i]);
+        }
+        if (ndev && !nofold) fail("the multi-device leg replays the fold-free final SNARK: pass nofold");
         const char *path = shapes_json && *shapes_json ? shapes_json : getenv("REEF_REPLAY_SHAPES");
         if (!path) fail("no replay shapes file given (argument or REEF_REPLAY_SHAPES)");
         if (reef_device_count() < 1) { put(std::string("no GPU: ") + reef_last_error()); return 3; }
         const Shape sh = load_shape(path, config && *config ? config : "cfg3");
         g_checked = 0;
-        put(replay_body(sh, nofold != 0, tables != 0, path));
+        put(replay_body(sh, nofold != 0, tables != 0, path, ordinals));
         return 0;
     } catch (const std::exception &e) {
         put(e.what());
         return 1;
     }
+}
+extern "C" __attribute__((visibility("default")))
+int reef_replay_run(const char *shapes_json, const char *config, int nofold, int tables, char *out, size_t cap) {
+    return reef_replay_run_devices(shapes_json, config, nofold, tables, nullptr, 0, out, cap);
 }
 
 #if !defined(REEF_REPLAY_NO_MAIN)
@@ -642,11 +786,18 @@ int main(int argc, char **argv) {
     const char *which = argc > 1 ? argv[1] : "cfg3";
     bool nofold = false, tables = false;
     std::string shapes;
+    int members = 0;
+    {   // an embedder's first call: eight hardware queues for the concurrent arguments, asked for before the first HIP call
+        reef_runtime_opts ro = {};
+        ro.hw_queues = 8;
+        (void)reef_runtime_init(&ro, nullptr);
+    }
     for (int i = 2; i < argc; ++i) {
         if (strcmp(argv[i], "nofold") == 0) nofold = true;
         else if (strcmp(argv[i], "tables") == 0) tables = true;       // the keys' byte tables are ready before the first MSM (a real run builds them in the background)
         else if (strncmp(argv[i], "shapes=", 7) == 0) shapes = argv[i] + 7;
-        else { fprintf(stderr, "usage: reef_replay [cfg1|cfg3|cfg4|cfg5] [nofold] [tables] [shapes=<replay_shapes.json>]\n"); return 2; }
+        else if (strncmp(argv[i], "devices=", 8) == 0) members = atoi(argv[i] + 8);     // the multi-device leg on N members (ordinal i mod the visible devices)
+        else { fprintf(stderr, "usage: reef_replay [cfg1|cfg3|cfg4|cfg5] [nofold] [tables] [devices=N] [shapes=<replay_shapes.json>]\n"); return 2; }
     }
     if (shapes.empty() && !getenv("REEF_REPLAY_SHAPES")) {   // the executable lives in reef_amd/_lib/: the shapes are two levels up, under tests/golden/
         char exe[4096];
@@ -658,8 +809,11 @@ int main(int argc, char **argv) {
             shapes = dir + "/../../tests/golden/replay_shapes.json";
         }
     }
-    std::vector<char> out(16384);
-    const int rc = reef_replay_run(shapes.empty() ? nullptr : shapes.c_str(), which, nofold, tables, out.data(), out.size());
+    std::vector<char> out(32768);
+    std::vector<int> ordinals;
+    const int visible = reef_device_count();
+    for (int i = 0; i < members && visible > 0; ++i) ordinals.push_back(i % visible);
+    const int rc = reef_replay_run_devices(shapes.empty() ? nullptr : shapes.c_str(), which, nofold, tables, ordinals.data(), ordinals.size(), out.data(), out.size());
     if (rc == 0) printf("%s\n", out.data());
     else fprintf(stderr, "reef_replay: %s\n", out.data());
     return rc;

@@ -29,14 +29,21 @@ def _load() -> ctypes.CDLL:
         lib = ctypes.CDLL(LIB_PATH)
         lib.reef_replay_run.restype = ctypes.c_int
         lib.reef_replay_run.argtypes = [ctypes.c_char_p, ctypes.c_char_p, ctypes.c_int, ctypes.c_int, ctypes.c_char_p, ctypes.c_size_t]
+        lib.reef_replay_run_devices.restype = ctypes.c_int
+        lib.reef_replay_run_devices.argtypes = [ctypes.c_char_p, ctypes.c_char_p, ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_int), ctypes.c_size_t,
+                                                ctypes.c_char_p, ctypes.c_size_t]
         _lib = lib
     return _lib
 
 
-def run(config: str = "cfg3", nofold: bool = True, tables: bool = False, shapes_path: str | None = None) -> dict:
-    """One replay; returns the harness's JSON line as a dict.  Raises on any failed call or mismatching commitment."""
-    buf = ctypes.create_string_buffer(16384)
-    rc = _load().reef_replay_run((shapes_path or SHAPES_PATH).encode(), config.encode(), int(nofold), int(tables), buf, len(buf))
+def run(config: str = "cfg3", nofold: bool = True, tables: bool = False, shapes_path: str | None = None, devices=None) -> dict:
+    """One replay; returns the harness's JSON line as a dict.  Raises on any failed call or mismatching commitment.
+    devices: ordinals (may repeat) for the multi-device leg -- the final SNARK's arguments placed whole on per-device contexts and the
+    document commitment through a device group (reef_msm_group_*), all from this one process; line["devices"] reports it."""
+    buf = ctypes.create_string_buffer(32768)
+    devs = list(devices or [])
+    arr = (ctypes.c_int * max(len(devs), 1))(*devs)
+    rc = _load().reef_replay_run_devices((shapes_path or SHAPES_PATH).encode(), config.encode(), int(nofold), int(tables), arr, len(devs), buf, len(buf))
     text = buf.value.decode(errors="replace")
     if rc != 0:
         raise RuntimeError(f"reef_replay_run({config}) failed with {rc}: {text}")

@@ -72,3 +72,32 @@ def test_world_size_must_match_gpus(gpu_lib):
            "--warmup", "0", "--no-cpu-baseline"]
     out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"), cwd=ROOT)
     assert out.returncode != 0 and "WORLD_SIZE=2" in out.stderr
+
+
+@pytest.mark.parametrize("members,logn", [(2, 16), (8, 14), (3, 17)])
+def test_bench_single_process_over_a_device_group(members, logn, gpu_lib):
+    """`bench.py --gpus N --single-process`: no launcher, no torch -- ONE process drives N members through reef_msm_group_* (what a Rust
+    prover can call; Reef is one process, src/backend/main.rs:82).  On a one-GPU box the ordinals repeat device 0 and the line says
+    that it is not a scaling measurement; every combined point is checked against its discrete logarithm."""
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(members), "--single-process", "--logn", str(logn), "--steps", "3", "--warmup", "1",
+           "--msms-per-step", "6"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [ln for ln in out.stdout.strip().splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    line = json.loads(lines[0])
+    cfg = line["config"]
+    assert line["n_gpus"] == members and cfg["check"] == "dlog-ok" and line["scaling"] == "weak"
+    assert cfg["mode"].startswith("single-process") and cfg["devices"] == [0] * members and cfg["distinct_devices"] == 1
+    assert "NOT a scaling measurement" in cfg["devices_note"] if members > 1 else cfg["devices_note"] is None
+    assert cfg["exchange"].startswith("peer") and cfg["total_points"] == members << logn
+    assert sum(cfg["key_points_per_member"]) == members << logn
+    ss = cfg["strong_scaling"]
+    assert ss["one_msm_points"] == 1 << logn and set(ss["speedup_vs_1"]) == {"windows", "points"}
+    for k in ("windows_ms_per_step", "points_ms_per_step", "windows_latency_ms", "points_latency_ms", "one_gpu_ms_per_msm"):
+        assert ss[k] > 0, k
+    if logn >= 16:
+        assert ss["hyrax_rows"]["check"] == "dlog-ok" and ss["hyrax_rows"]["rows"] == 4096
+    assert line["value"] > 0 and line["roofline"]["kernel_ms"] > 0 and cfg["host_scalars_ms_per_msm"] > 0
+    refused = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT, env=dict(os.environ, WORLD_SIZE="2"))
+    assert refused.returncode != 0 and "WITHOUT torch.distributed.run" in refused.stderr

@@ -59,6 +59,28 @@ def test_replay_with_generator_folds(gpu_lib):
     assert "generator fold" in line["ipa"]
 
 
+@pytest.mark.parametrize("cfg,members", [("cfg4", 3), ("cfg3", 2), ("cfg4", 8)])
+def test_replay_multi_device_leg_in_one_process(cfg, members, gpu_lib):
+    """`reef_replay cfgN nofold devices=M`: the final SNARK's arguments placed whole on M members (per-device contexts, one caller
+    thread each; framework.rs:695-721) and the document commitment through a device group (commitment.rs:187), from ONE process --
+    what a Rust prover can call.  A test box has one GPU: the ordinals repeat device 0 and the line says so."""
+    from reef_amd import replay
+    line = replay.run(cfg, nofold=True, devices=[0] * members)
+    dv = line["devices"]
+    assert dv["members"] == members and dv["distinct_devices"] == 1 and dv["visible_devices"] >= 1
+    placed = dv["final_snark_placed"]
+    assert [a["argument"] for a in placed] == ["ipa_pallas", "ipa_vesta", "consistency"]
+    assert all(a["device"] == 0 and a["alone_ms"] > 0 for a in placed)
+    assert placed[0]["points"] == line["key_pallas"] and placed[1]["points"] == line["key_vesta"]
+    assert 0 < dv["three_arguments_on_devices_ms"] < dv["three_arguments_one_after_the_other_ms"] * 1.2
+    assert dv["commit_rows_checked_against_one_device"] is True and dv["commit_hyrax_group_ms"] > 0
+    assert dv["group_exchange"].startswith("peer")
+    with pytest.raises(RuntimeError):
+        replay.run(cfg, nofold=True, devices=[0, 99])               # an ordinal that is not visible
+    with pytest.raises(RuntimeError):
+        replay.run("cfg1", nofold=False, devices=[0, 0])            # the leg replays the fold-free final SNARK
+
+
 def test_replay_executable(gpu_lib):
     """The same harness as a program (what profiles/*replay*.jsonl were recorded with): exit code 0 and one JSON line."""
     exe = os.path.join(ROOT, "reef_amd", "_lib", "reef_replay")
@@ -66,5 +88,8 @@ def test_replay_executable(gpu_lib):
     assert out.returncode == 0, out.stderr[-2000:]
     line = json.loads(out.stdout.strip().splitlines()[-1])
     assert line["commitments_checked_against_dlog"] >= 24
+    dev = subprocess.run([exe, "cfg4", "nofold", "devices=4"], capture_output=True, text=True, timeout=600)
+    assert dev.returncode == 0, dev.stderr[-2000:]
+    assert json.loads(dev.stdout.strip().splitlines()[-1])["devices"]["members"] == 4
     bad = subprocess.run([exe, "cfg3", "nofold", "shapes=/nonexistent.json"], capture_output=True, text=True, timeout=600)
     assert bad.returncode != 0 and "shapes" in bad.stderr
