@@ -518,3 +518,80 @@ def test_structured_table_at_cfg4_shape(gpu_lib, monkeypatch):
                     sc.fold(i, challenges[i - 1])
             transcripts.append((tr, sc.read(0, 1)[0], sc.read(1, 1)[0]))
     assert transcripts[0] == transcripts[1] == transcripts[2]
+
+
+# ---------------------------------------------------------------- the one-launch rounds under load ----
+_STRESS_GRIDS = {
+    # name: (ell, environment) -- REEF_SC_ITEMS=1 gives a round ceil(pairs / 256) workgroups up to REEF_SC_BLOCKS, so a step of 2^ell entries
+    # walks through every power of two below the cap; REEF_SC_SPLIT_MAX=0 keeps the dense kernels on the small rounds
+    "2-blocks": (12, {"REEF_SC_BLOCKS": "2", "REEF_SC_ITEMS": "1", "REEF_SC_SPLIT_MAX": "0"}),
+    "3-blocks": (18, {"REEF_SC_BLOCKS": "3", "REEF_SC_ITEMS": "1", "REEF_SC_SPLIT_MAX": "0"}),
+    "16-blocks": (16, {"REEF_SC_BLOCKS": "16", "REEF_SC_ITEMS": "1", "REEF_SC_SPLIT_MAX": "0"}),
+    "64-blocks": (18, {"REEF_SC_BLOCKS": "64", "REEF_SC_ITEMS": "1", "REEF_SC_SPLIT_MAX": "0"}),
+    "up-to-1024-blocks": (20, {"REEF_SC_BLOCKS": "2048", "REEF_SC_ITEMS": "1", "REEF_SC_SPLIT_MAX": "0", "REEF_SC_ONE_LAUNCH_MAX": "8192"}),   # every XCD many times over
+    "split-rounds-64-blocks": (17, {}),                                                                                                         # the shipped grid: four-wave items, up to 64 workgroups
+    "split-rounds-1024-blocks": (18, {"REEF_SC_SPLIT_BLOCKS": "1024", "REEF_SC_SPLIT_MAX": "65536"}),
+    "rank-one-accumulator-sets": (16, {"REEF_SC_RANK1_MIN_POW": "1"}),                                                                          # k_sc_r1_final's 16 sets (a kernel boundary orders those)
+}
+
+
+def _stress(name, steps, order, load=True, extra=()):
+    import json
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    ell, env = _STRESS_GRIDS[name]
+    e = dict(os.environ, REEF_SC_FENCE=str(order), **env)
+    out = subprocess.run([os.path.join(root, "reef_amd", "_lib", "sc_stress"), str(ell), str(steps)] + (["load"] if load else []) + list(extra),
+                         capture_output=True, text=True, timeout=900, env=e)
+    assert out.returncode in (0, 1), out.stderr[-2000:]
+    line = json.loads(out.stdout.strip().splitlines()[-1])
+    assert line["ell"] == ell and line["steps"] == steps and line["REEF_SC_FENCE"] == str(order)
+    return line
+
+
+@pytest.mark.parametrize("name,steps", [("2-blocks", 6000), ("3-blocks", 5000), ("16-blocks", 5000), ("64-blocks", 5000), ("up-to-1024-blocks", 3000),
+                                        ("split-rounds-64-blocks", 5000), ("split-rounds-1024-blocks", 3000), ("rank-one-accumulator-sets", 3000)])
+def test_one_launch_rounds_under_load(name, steps, gpu_lib):
+    """The fence-free hand-over of a multi-block one-launch round (sc_round_epilogue, REEF_SC_FENCE=0: the shipped form) repeated on the
+    same inputs while two other caller threads run k_accum0 and stream a 2^24-entry table: ~5.8 x 10^5 rounds in all, every coefficient
+    triple against the two-launch form of the same step (a kernel boundary instead of the ticket).  ONE mismatch and the default goes
+    back to a fenced form (sumcheck_kernels.inc: SC_ORDER_*)."""
+    line = _stress(name, steps, 0)
+    assert line["mismatched_steps"] == 0 and line["mismatched_values"] == 0, line
+    assert line["load_msms"] > 0 and line["load_streaming_rounds"] > 0, line          # the other streams really ran beside it
+
+
+@pytest.mark.parametrize("order", [1, 2])
+@pytest.mark.parametrize("name", ["3-blocks", "64-blocks", "split-rounds-64-blocks"])
+def test_one_launch_rounds_fenced_forms(name, order, gpu_lib):
+    """REEF_SC_FENCE=1 (__threadfence before the ticket) and =2 (acq_rel ticket: the form the HIP memory model blesses) stay built and
+    tested: the switch an embedder -- or the next round -- flips if the fence-free form is ever caught."""
+    line = _stress(name, 600, order)
+    assert line["mismatched_steps"] == 0, line
+
+
+def test_stress_reference_transcript_is_the_oracles(gpu_lib):
+    """What sc_stress compares against is itself checked: its two-launch reference transcript for a 2^12-entry table equals
+    oracle/sumcheck_oracle.py's on the same inputs (table from the library's seeded generator, the inputs of make_inputs())."""
+    from reef_amd import msm
+    from reef_amd.sumcheck import array_to_ints
+    ell = 12
+    line = _stress("2-blocks", 2, 0, load=False, extra=("print",))
+    got = [int(h, 16) for h in line["transcript"]]
+    table = array_to_ints(msm.gen_scalars("pallas", 0x7AB1E + ell, 1 << ell, kind=0, mont=False))
+    limbs = lambda l0, l1, l2, l3: l0 | (l1 << 64) | (l2 << 128) | (l3 << 192)
+    nq = 9
+    rs = [limbs(0x9e3779b97f4a7c15 * (i + 1) & (2**64 - 1), 0x1234 + i, 0x55aa * i, 0x0123456789abcdef) for i in range(nq + 1)]
+    qs = [((0x2545F4914F6CDD1D * (i + 7)) & (2**64 - 1)) >> (64 - ell) for i in range(nq)]
+    qs[1] = qs[0]
+    last_q = [limbs(0xabcdef12345 + j, 0x77 * j, 0xfeed, 0x0fedcba987654321) for j in range(ell)]
+    chal = [limbs(0x5851f42d4c957f2d + i, 0x14057b7ef767814f, 0x0123456789abcdef, 0x0fedcba987654321) for i in range(1, ell + 1)]
+    assert all(v < Q for v in rs + last_q + chal)
+    t, e = list(table), gen_eq_table(rs, qs, last_q)
+    want = []
+    for i in range(1, ell + 1):
+        want += list(linear_mle_coeffs(t, e, ell, i))
+        linear_mle_fold(t, e, ell, i, chal[i - 1])
+    want.append(t[0])
+    assert got == want
