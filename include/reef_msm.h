@@ -88,6 +88,14 @@ typedef struct {
 } reef_key_cache_stats;
 void reef_key_cache_info(reef_key_cache_stats *out);
 void reef_key_cache_clear(void);
+/* Where the calls served from a resident key spent their time on the HOST, summed over all calling threads since the last reset
+ * (nanoseconds; diagnostics: tools/seam_bench): nominating the key (sampled hash + table lookup), enqueueing the MSM (includes the
+ * staging of the caller's pageable scalars), confirming the caller's bytes (memcmp against the retained copy, beside the GPU), and
+ * waiting for the result. */
+typedef struct {
+    uint64_t calls, nominate_ns, enqueue_ns, confirm_ns, wait_ns, reserved[3];
+} reef_key_cache_timing;
+void reef_key_cache_timing_get(reef_key_cache_timing *out, int reset);
 
 /* ---------------------------------------------------------------------------------------------
  * (2) Resident-key handle API.

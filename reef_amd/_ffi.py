@@ -52,6 +52,10 @@ class GroupInfo(ctypes.Structure):
                 ("reserved", c_uint32 * 3), ("key_points", c_uint64 * 16)]
 
 
+class KeyCacheTiming(ctypes.Structure):
+    _fields_ = [(n, c_uint64) for n in ("calls", "nominate_ns", "enqueue_ns", "confirm_ns", "wait_ns")] + [("reserved", c_uint64 * 3)]
+
+
 class KeyCacheStats(ctypes.Structure):
     _fields_ = [(n, c_uint64) for n in ("entries", "resident_keys", "resident_bytes", "builds", "hits", "clones", "misspeculated", "reserved")]
 
@@ -115,6 +119,7 @@ def load() -> ctypes.CDLL:
         "reef_abi_version": (c_uint32, []),
         "reef_key_cache_info": (None, [POINTER(KeyCacheStats)]),
         "reef_key_cache_clear": (None, []),
+        "reef_key_cache_timing_get": (None, [POINTER(KeyCacheTiming), c_int]),
         "reef_runtime_init": (c_int, [POINTER(RuntimeOpts), POINTER(RuntimeInfo)]),
         "reef_msm_ctx_last_timing": (c_int, [vp, POINTER(c_float), POINTER(c_float)]),
         "reef_msm_ctx_enable_timing": (c_int, [vp, c_int]),

@@ -9,8 +9,12 @@
 #include <string.h>
 
 #include <atomic>
+#include <chrono>
+#include <condition_variable>
+#include <deque>
 #include <memory>
 #include <mutex>
+#include <thread>
 
 #include "common.h"
 #include "keccak.h"
@@ -439,61 +443,123 @@ namespace {
 // REEF_MSM_KEY_CACHE=0 turns it off.
 //
 // Hashes only NOMINATE an entry; a hit is CONFIRMED by comparing every byte the caller passed with the copy retained next to
-// the resident key, so a collision costs time, never a wrong commitment.  Round 4 made the confirmation free for Reef's sizes:
-// the caller's thread enqueues the MSM on the nominated key FIRST (speculation), compares the bytes while the GPU works --
-// on the host against a host copy for keys up to 2^17 points (8 MB: no base crosses PCIe on a hit), on the device on the same
-// stream for larger ones (an upload is faster there than a one-core memcmp) -- and takes the result only if they were equal;
-// otherwise the call is served again on the plain path.  One stream synchronisation per call instead of four.
+// the resident key, so a collision costs time, never a wrong commitment.  The confirmation is free: the caller's thread enqueues
+// the MSM on the nominated key FIRST (speculation) and compares the bytes while the GPU works -- always on the HOST, against a host
+// copy (round 5: no base crosses PCIe on a hit, whatever the key's size; round 4 uploaded keys above 2^17 points to compare them
+// on the device, 1.2 ms of a 3.6 ms call at 2^20 points).  Keys of more than 4 MiB are compared in 1 MiB pieces by the caller and
+// a few helper threads of the process (REEF_MSM_CMP_THREADS, default up to 8: 64 MiB in ~1 ms, beside the scalars' upload and the
+// MSM).  The result is taken only if every byte was equal; otherwise the call is served again on the plain path.
 //
-// The table of resident keys is ONE per process (round 4; nova-snark reaches this symbol from the prover thread and from
-// rayon workers, src/backend/framework.rs:110,668,695): a key is built once, by the thread that brings its second
-// appearance, and every caller thread serves it through a clone of its own -- a HIP stream and a workspace on the shared,
-// read-only tables (reef_msm_ctx_clone once, reef_msm_ctx_attach when the thread's next call is on another key: its
-// workspace is sized once, whatever the number of keys).  16 callers cost one warm-up and one copy of the key (round 3: one of
-// each per thread).  The table lock is held for the lookup only, never across HIP work; while a key is being built the other threads
-// serve it on the plain path.  Device memory is charged to one budget (REEF_MSM_KEY_CACHE_MB, default 16384 = 16 GiB of the
-// 288 GB); an allocation failure anywhere on this path empties the table and the thread's clones and retries once on the
-// plain, uncached path before the symbol gives up.
+// The table of resident keys is ONE per process (nova-snark reaches this symbol from the prover thread and from rayon workers,
+// src/backend/framework.rs:110,668,695): a key is built once, by the thread that brings its second appearance, and every caller
+// thread serves it through a context of its own attached to the key of the moment (reef_msm_ctx_attach: O(1)).  The table lock is
+// held for lookups only, NEVER across HIP work or a destructor that does HIP work: entries that leave the table are destroyed
+// after the lock is released, and an entry lives on -- charged to the budget -- until the last thread whose context is
+// attached to it has moved on or ended.  Device memory is charged to one budget (REEF_MSM_KEY_CACHE_MB, default 16384), the host
+// copies to another (REEF_MSM_KEY_HOST_MB, default 4096); an allocation failure anywhere on this path empties the table and the
+// thread's contexts and retries once on the plain, uncached path before the symbol gives up.
 struct SharedKey {
     int curve = 0, device = 0;
     uint64_t hs = 0;                   // hash of n and 64 sampled points: nominates on the fast path
     uint64_t hf[2] = {0, 0};           // hash of every byte: identifies the entry on the slow path
     size_t n = 0;
-    reef_msm_ctx *master = nullptr;    // owns the reference on the pre-shifted tables the clones share
-    void *host_copy = nullptr;         // the bytes the resident key was built from: on the host (keys up to HOST_CMP_MAX_POINTS) ...
-    void *raw = nullptr;               // ... or on the device (larger keys)
-    size_t charged = 0;                // device bytes charged to the process-wide budget
+    reef_msm_ctx *master = nullptr;    // owns the reference on the pre-shifted tables the threads' contexts share
+    void *host_copy = nullptr;         // the bytes the resident key was built from
+    size_t charged = 0, host_charged = 0;   // device / host bytes charged to the process-wide budgets
     std::atomic<uint64_t> last_use{0};
     std::atomic<int> state{0};         // 0 nominated (seen, no copy), 1 being built, 2 resident, 3 evicted, 4 not worth another try
     uint32_t seen = 1;                 // under the table lock
     ~SharedKey();
 };
-std::atomic<size_t> g_cache_bytes{0};
+std::atomic<size_t> g_cache_bytes{0}, g_host_bytes{0};
 std::atomic<uint64_t> g_cache_builds{0}, g_cache_hits{0}, g_cache_clones{0}, g_cache_misspeculated{0};
+std::atomic<uint64_t> g_seam_calls{0}, g_seam_nominate_ns{0}, g_seam_enqueue_ns{0}, g_seam_confirm_ns{0}, g_seam_wait_ns{0};
+static inline uint64_t now_ns() { return (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+// Runs on whichever thread drops the last reference -- never under the table lock (the table hands evicted entries to its caller).
 SharedKey::~SharedKey() {
     free(host_copy);
+    g_host_bytes -= host_charged;
     if (g_process_exiting.load()) return;          // the driver reclaims everything
-    reef_msm_ctx_destroy(master);
-    if (raw) reef_device_free(raw);
+    reef_msm_ctx_destroy(master);                  // the last handle on the tables: they are freed here, and only now is the budget released
     g_cache_bytes -= charged;
 }
-static size_t cache_budget() {
-    static const size_t b = [] {
-        const char *e = getenv("REEF_MSM_KEY_CACHE_MB");
-        return (size_t)(e ? strtoull(e, nullptr, 10) : 16384ull) << 20;
-    }();
-    return b;
+static size_t env_mb(const char *name, unsigned long long dflt) {
+    const char *e = getenv(name);
+    return (size_t)(e && *e ? strtoull(e, nullptr, 10) : dflt) << 20;
 }
-constexpr size_t KEY_CACHE_MIN_POINTS = 1024, KEY_TABLE_ENTRIES = 16, HOST_CMP_MAX_POINTS = (size_t)1 << 17;
+static size_t cache_budget() { static const size_t b = env_mb("REEF_MSM_KEY_CACHE_MB", 16384); return b; }
+static size_t host_budget() { static const size_t b = env_mb("REEF_MSM_KEY_HOST_MB", 4096); return b; }
+constexpr size_t KEY_CACHE_MIN_POINTS = 1024, KEY_TABLE_ENTRIES = 16;
+constexpr size_t CMP_PIECE = (size_t)1 << 20, CMP_PARALLEL_MIN = (size_t)4 << 20;
+
+// ---- the byte comparison of a large key, in pieces, by the caller and the process's helper threads
+struct CompareJob {
+    const char *a = nullptr, *b = nullptr;
+    size_t bytes = 0, pieces = 0;
+    std::atomic<size_t> next{0}, done{0};
+    std::atomic<int> differ{0};
+    void work() {
+        for (;;) {
+            const size_t i = next.fetch_add(1, std::memory_order_relaxed);
+            if (i >= pieces) return;                   // nothing of a / b is touched beyond this point: the caller may be gone
+            const size_t off = i * CMP_PIECE, len = std::min(CMP_PIECE, bytes - off);
+            if (!differ.load(std::memory_order_relaxed) && memcmp(a + off, b + off, len) != 0) differ.store(1, std::memory_order_relaxed);
+            done.fetch_add(1, std::memory_order_release);
+        }
+    }
+    bool finished() const { return done.load(std::memory_order_acquire) == pieces; }
+};
+struct ComparePool {
+    std::mutex mu;
+    std::condition_variable cv;
+    std::deque<std::shared_ptr<CompareJob>> q;
+    size_t nthreads = 0;
+    ComparePool() {
+        const char *e = getenv("REEF_MSM_CMP_THREADS");
+        const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
+        nthreads = e && *e ? (size_t)std::min<long>(64, std::max<long>(0, atol(e))) : (size_t)std::min(8u, std::max(2u, hw / 4));
+        for (size_t i = 0; i < nthreads; ++i)
+            std::thread([this] {
+                for (;;) {
+                    std::shared_ptr<CompareJob> j;
+                    {
+                        std::unique_lock<std::mutex> lk(mu);
+                        cv.wait(lk, [&] { return !q.empty(); });
+                        j = std::move(q.front());
+                        q.pop_front();
+                    }
+                    j->work();
+                }
+            }).detach();                               // they sleep on the queue for the life of the process; never joined (static destructors run after HIP)
+    }
+    void help(const std::shared_ptr<CompareJob> &j) {
+        const size_t helpers = std::min(nthreads, j->pieces > 1 ? j->pieces - 1 : 0);
+        if (!helpers) return;
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            for (size_t i = 0; i < helpers; ++i) q.push_back(j);
+        }
+        cv.notify_all();
+    }
+};
+static ComparePool &compare_pool() {
+    static ComparePool *p = new ComparePool();
+    return *p;
+}
+
 struct KeyTable {
     std::mutex mu;
     std::vector<std::shared_ptr<SharedKey>> keys;
     std::atomic<uint64_t> tick{0};
-    // every entry leaves the table; a key lives on until the last thread that holds a clone of it has let go
+    // every entry leaves the table; the entries are destroyed AFTER the lock has been released (their destructors wait for and
+    // free device memory), and a key lives on until the last thread attached to it has let go
     void clear() {
-        std::lock_guard<std::mutex> lk(mu);
-        for (auto &k : keys) k->state.store(3);
-        keys.clear();
+        std::vector<std::shared_ptr<SharedKey>> gone;
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            for (auto &k : keys) k->state.store(3);
+            gone.swap(keys);
+        }
     }
 };
 static KeyTable &key_table() {
@@ -532,26 +598,21 @@ static void full_hash(const reef_affine *p, size_t n, uint64_t out[2]) {
 struct TlsCtx {
     reef_msm_ctx *ctx[2] = {nullptr, nullptr};      // plain path: re-keyed on every call
     reef_msm_ctx *rctx[2] = {nullptr, nullptr};     // resident path: this thread's stream and workspace, attached to whichever shared key a call nominates
+    std::shared_ptr<SharedKey> attached[2];         // the key rctx is attached to: it (and its share of the budget) lives while any thread's context is on its tables
     int ctx_dev[2] = {-1, -1}, rctx_dev[2] = {-1, -1};
-    reef_jacobian *pinned = nullptr;                // host-mapped: the speculative result lands here; word 24 is the verdict of a device compare
-    void *dev_flag = nullptr;
-    void *stage = nullptr;                          // device staging of the caller's bases (keys compared on the device)
-    size_t stage_cap = 0;
-    int stage_dev = -1;
+    reef_jacobian *pinned = nullptr;                // host-mapped: the speculative result lands here
     void drop_resident() {
-        for (auto *&c : rctx) { reef_msm_ctx_destroy(c); c = nullptr; }
-    }
-    void drop_stage() {
-        if (stage) reef_device_free(stage);
-        stage = nullptr; stage_cap = 0; stage_dev = -1;
+        for (int c = 0; c < 2; ++c) {
+            reef_msm_ctx_destroy(rctx[c]);
+            rctx[c] = nullptr;
+            attached[c].reset();                       // after the context: the key's destructor frees what the context was reading
+        }
     }
     ~TlsCtx() {
-        if (g_process_exiting.load()) return;      // process teardown: never call into HIP
+        if (g_process_exiting.load()) return;          // process teardown: never call into HIP (the keys' destructors look at the same flag)
         for (auto *c : ctx) reef_msm_ctx_destroy(c);
         drop_resident();
-        drop_stage();
         if (pinned) (void)hipHostFree(pinned);
-        if (dev_flag) reef_device_free(dev_flag);
     }
 };
 thread_local TlsCtx g_tls;
@@ -574,32 +635,31 @@ static reef_status pippenger_plain(int curve, reef_jacobian *out, const reef_aff
 // never fatal -- the key keeps being served on the plain path.
 static void build_resident(const std::shared_ptr<SharedKey> &k, const reef_affine *points) {
     const size_t bytes = k->n * sizeof(reef_affine);
-    const bool on_host = k->n <= HOST_CMP_MAX_POINTS;
     uint32_t T = 1;
     (void)reef_msm_plan_for(k->n, 0, 1, nullptr, nullptr, nullptr, &T);
-    const size_t cost = bytes * ((size_t)T + (on_host ? 0 : 1));   // T pre-shifted tables (+ the raw copy of a large key)
+    const size_t cost = bytes * (size_t)T;             // T pre-shifted tables
     int done = 4;
-    if (g_cache_bytes.load() + cost <= cache_budget()) {
+    if (g_cache_bytes.load() + cost <= cache_budget() && g_host_bytes.load() + bytes <= host_budget()) {
         reef_msm_opts o = {};
         o.bucket_groups = 1;
         o.byte_tables = 2;                             // never for a key the caller did not create: 256 KiB per point would dwarf the budget
         o.device = k->device;
-        void *copy = on_host ? malloc(bytes) : reef_device_alloc(bytes);
+        void *copy = malloc(bytes);
         reef_msm_ctx *master = nullptr;
         bool ok = copy != nullptr;
-        if (ok && on_host) memcpy(copy, points, bytes);
-        else if (ok) ok = reef_memcpy(copy, points, bytes, REEF_DEVICE, REEF_HOST) == REEF_OK;
+        if (ok) memcpy(copy, points, bytes);
         ok = ok && reef_msm_ctx_create(&master, k->curve, points, k->n, REEF_HOST, &o) == REEF_OK;
         if (ok) {
-            (on_host ? k->host_copy : k->raw) = copy;
+            k->host_copy = copy;
             k->master = master;
             k->charged = cost;
+            k->host_charged = bytes;
             g_cache_bytes += cost;
+            g_host_bytes += bytes;
             g_cache_builds += 1;
             done = 2;
-        } else if (copy) {
-            if (on_host) free(copy);
-            else reef_device_free(copy);
+        } else {
+            free(copy);
         }
     }
     int expect = 1;                                    // an entry evicted meanwhile (state 3) stays evicted
@@ -612,38 +672,43 @@ static reef_status pippenger_resident(const std::shared_ptr<SharedKey> &k, reef_
     const size_t bytes = npoints * sizeof(reef_affine);
     const int curve = k->curve;
     reef_msm_ctx *&c = g_tls.rctx[curve];
-    if (c && g_tls.rctx_dev[curve] != k->device) { reef_msm_ctx_destroy(c); c = nullptr; }
+    if (c && g_tls.rctx_dev[curve] != k->device) { reef_msm_ctx_destroy(c); c = nullptr; g_tls.attached[curve].reset(); }
     if (!c) {
         REEF_TRY(reef_msm_ctx_clone(&c, k->master));
         g_tls.rctx_dev[curve] = k->device;
         g_cache_clones += 1;
-    } else {
+    } else if (g_tls.attached[curve] != k) {
         REEF_TRY(reef_msm_ctx_attach(c, k->master));   // O(1): the thread's stream and workspace on another key's tables
     }
+    g_tls.attached[curve] = k;                         // the key this thread let go of may end here (its last reference): outside every lock
     if (!g_tls.pinned && hipHostMalloc((void **)&g_tls.pinned, 128, hipHostMallocDefault) != hipSuccess) {
         (void)hipGetLastError();
         g_tls.pinned = nullptr;
         set_error("hipHostMalloc failed");
         return REEF_ERR_OOM;
     }
-    volatile uint32_t *verdict = reinterpret_cast<volatile uint32_t *>(g_tls.pinned + 1);
-    if (k->raw) {                                      // a large key: upload and compare on the thread's stream, ahead of the MSM
-        if (bytes > g_tls.stage_cap || g_tls.stage_dev != k->device) {
-            g_tls.drop_stage();
-            g_tls.stage = reef_device_alloc(bytes + bytes / 8);
-            if (!g_tls.stage) return REEF_ERR_OOM;
-            g_tls.stage_cap = bytes + bytes / 8;
-            g_tls.stage_dev = k->device;
-        }
-        if (!g_tls.dev_flag && !(g_tls.dev_flag = reef_device_alloc(16))) return REEF_ERR_OOM;
-        *verdict = 1;
-        REEF_TRY(vt(curve)->bytes_differ_async(reef_msm_ctx_stream(c), points, g_tls.stage, k->raw, bytes, g_tls.dev_flag, (void *)verdict));
+    const uint64_t t0 = now_ns();
+    std::shared_ptr<CompareJob> job;
+    if (bytes >= CMP_PARALLEL_MIN) {                   // a large key: the helpers start on it while this thread stages the scalars
+        job = std::make_shared<CompareJob>();
+        job->a = (const char *)points; job->b = (const char *)k->host_copy; job->bytes = bytes; job->pieces = (bytes + CMP_PIECE - 1) / CMP_PIECE;
+        compare_pool().help(job);
     }
-    REEF_TRY(reef_msm(c, scalars, npoints, REEF_HOST, is_mont, g_tls.pinned, REEF_DEVICE));   // enqueued; the result goes to host-mapped memory
-    bool eq = true;
-    if (k->host_copy) eq = memcmp(points, k->host_copy, bytes) == 0;                          // while the GPU works
+    const reef_status issued = reef_msm(c, scalars, npoints, REEF_HOST, is_mont, g_tls.pinned, REEF_DEVICE);   // enqueued; the result goes to host-mapped memory
+    const uint64_t t1 = now_ns();
+    bool eq;
+    if (job) {                                         // the caller's pointers must outlive every piece in flight, whatever `issued` says
+        job->work();
+        while (!job->finished()) std::this_thread::yield();
+        eq = job->differ.load() == 0;
+    } else {
+        eq = memcmp(points, k->host_copy, bytes) == 0; // while the GPU works
+    }
+    const uint64_t t2 = now_ns();
+    REEF_TRY(issued);
     REEF_TRY(reef_msm_ctx_sync(c));
-    if (k->raw) eq = *verdict == 0;
+    const uint64_t t3 = now_ns();
+    g_seam_calls += 1; g_seam_enqueue_ns += t1 - t0; g_seam_confirm_ns += t2 - t1; g_seam_wait_ns += t3 - t2;
     *same = eq;
     if (eq) {
         memcpy(out, g_tls.pinned, sizeof(reef_jacobian));
@@ -658,6 +723,7 @@ static reef_status pippenger_cached(int curve, reef_jacobian *out, const reef_af
     int dev = 0;
     REEF_HIP_TRY(hipGetDevice(&dev));
     KeyTable &tab = key_table();
+    const uint64_t tn = now_ns();
     const uint64_t hs = sampled_hash(points, npoints);
     std::shared_ptr<SharedKey> k;
     {                                                  // fast path: the most recently used resident key the samples nominate
@@ -668,6 +734,7 @@ static reef_status pippenger_cached(int curve, reef_jacobian *out, const reef_af
                 k = e;
         if (k) k->last_use.store(++tab.tick);
     }
+    g_seam_nominate_ns += now_ns() - tn;
     if (k) {
         bool same = false;
         REEF_TRY(pippenger_resident(k, out, points, npoints, scalars, is_mont, &same));
@@ -677,6 +744,7 @@ static reef_status pippenger_cached(int curve, reef_jacobian *out, const reef_af
     uint64_t hf[2];
     full_hash(points, npoints, hf);
     bool builder = false;
+    std::shared_ptr<SharedKey> evicted;                // destroyed after the lock below has been released (declared before it)
     {
         std::lock_guard<std::mutex> lk(tab.mu);
         const uint64_t now = ++tab.tick;
@@ -698,6 +766,7 @@ static reef_status pippenger_cached(int curve, reef_jacobian *out, const reef_af
                     }
                 if (lru < tab.keys.size()) {
                     tab.keys[lru]->state.store(3);
+                    evicted = std::move(tab.keys[lru]);
                     tab.keys.erase(tab.keys.begin() + lru);
                 }
             }
@@ -709,6 +778,7 @@ static reef_status pippenger_cached(int curve, reef_jacobian *out, const reef_af
             }
         }
     }
+    evicted.reset();                                   // here: HIP work of the destructor (if this was the last reference) outside the lock
     if (k && !builder && k->state.load(std::memory_order_acquire) == 2) {   // resident, but not what the samples nominated first
         bool same = false;
         REEF_TRY(pippenger_resident(k, out, points, npoints, scalars, is_mont, &same));
@@ -730,7 +800,6 @@ static reef_status pippenger_try(int curve, reef_jacobian *out, const reef_affin
     if (st == REEF_ERR_OOM) {                           // give the cache's memory back and serve the call uncached
         key_table().clear();
         g_tls.drop_resident();
-        g_tls.drop_stage();
         st = pippenger_plain(curve, out, points, npoints, scalars, is_mont);
     }
     return st;
@@ -759,6 +828,14 @@ void reef_key_cache_info(reef_key_cache_stats *out) {
     out->reserved = 0;
 }
 void reef_key_cache_clear(void) { key_table().clear(); }
+void reef_key_cache_timing_get(reef_key_cache_timing *out, int reset) {
+    if (out) {
+        memset(out, 0, sizeof *out);
+        out->calls = g_seam_calls.load(); out->nominate_ns = g_seam_nominate_ns.load(); out->enqueue_ns = g_seam_enqueue_ns.load();
+        out->confirm_ns = g_seam_confirm_ns.load(); out->wait_ns = g_seam_wait_ns.load();
+    }
+    if (reset) { g_seam_calls = 0; g_seam_nominate_ns = 0; g_seam_enqueue_ns = 0; g_seam_confirm_ns = 0; g_seam_wait_ns = 0; }
+}
 
 void mult_pippenger_pallas(reef_jacobian *out, const reef_affine *points, size_t npoints, const reef_fe *scalars, bool is_mont) {
     pippenger(REEF_PALLAS, out, points, npoints, scalars, is_mont);

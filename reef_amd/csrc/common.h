@@ -249,9 +249,6 @@ struct CurveVTable {
     // row N1: commitment-key derivation (hash to the curve; coordinates in the curve's base field)
     reef_status (*derive_generators)(const uint8_t *label, size_t label_len, size_t n, const reef_keygen_params *kp, bool is_mont, reef_affine *out,
                                      int out_loc);
-    // on `stream`: host_src -> dev_stage, then *pinned_verdict = (dev_stage differs from dev_ref) ? 1 : 0 (asynchronous)
-    reef_status (*bytes_differ_async)(void *stream, const void *host_src, void *dev_stage, const void *dev_ref, size_t bytes, void *dev_flag,
-                                      void *pinned_verdict);
     reef_status (*plan_for)(size_t n, uint32_t c_opt, uint32_t g_opt, uint32_t *c, uint32_t *w, uint32_t *g, uint32_t *t);
 };
 

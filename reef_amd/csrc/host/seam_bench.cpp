@@ -1,0 +1,109 @@
+// seam_bench -- the pasta-msm drop-in symbols under the callers Reef really has: T threads inside mult_pippenger_pallas at once on ONE
+// returning key (nova-snark's prover thread and rayon workers: src/backend/framework.rs:110, 668, 695), host buffers in, commitment
+// back (PCIe-inclusive).  C++ so that no interpreter lock sits in the measurement.  Per (size, thread count): `calls` calls per thread,
+// `reps` repetitions; reports the MEDIAN, minimum and maximum aggregate rate over the repetitions, the median per-call latency, and where
+// the calls spent their host time (reef_key_cache_timing_get: nominate / enqueue incl. the staging of the pageable scalars / confirm
+// the key's bytes / wait).  One line of JSON per (size, threads).
+//
+// usage: seam_bench [sizes=24918,65536] [threads=1,4,8] [calls=500] [reps=5]
+#include <algorithm>
+#include <atomic>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "reef_msm.h"
+
+#define CK(x)                                                                                                    \
+    do {                                                                                                         \
+        reef_status s_ = (x);                                                                                    \
+        if (s_ != REEF_OK) { fprintf(stderr, "seam_bench: %s failed: %s\n", #x, reef_last_error()); exit(3); }    \
+    } while (0)
+
+static std::vector<long> list_of(const char *s) {
+    std::vector<long> v;
+    while (*s) {
+        v.push_back(atol(s));
+        const char *c = strchr(s, ',');
+        if (!c) break;
+        s = c + 1;
+    }
+    return v;
+}
+using clk = std::chrono::steady_clock;
+
+int main(int argc, char **argv) {
+    std::vector<long> sizes = {3000, 24918, 65536, 262144}, threads = {1, 4, 8};
+    long calls = 500, reps = 5;
+    for (int i = 1; i < argc; ++i) {
+        if (!strncmp(argv[i], "sizes=", 6)) sizes = list_of(argv[i] + 6);
+        else if (!strncmp(argv[i], "threads=", 8)) threads = list_of(argv[i] + 8);
+        else if (!strncmp(argv[i], "calls=", 6)) calls = atol(argv[i] + 6);
+        else if (!strncmp(argv[i], "reps=", 5)) reps = atol(argv[i] + 5);
+        else { fprintf(stderr, "usage: seam_bench [sizes=a,b] [threads=1,4,8] [calls=500] [reps=5]\n"); return 2; }
+    }
+    {
+        reef_runtime_opts ro = {};
+        ro.hw_queues = 8;
+        (void)reef_runtime_init(&ro, nullptr);
+    }
+    if (reef_device_count() < 1) { fprintf(stderr, "seam_bench: no GPU\n"); return 3; }
+    for (long n : sizes) {
+        std::vector<reef_affine> bases((size_t)n);
+        CK(reef_gen_bases(REEF_PALLAS, 11 + n % 97, 3, (size_t)n, bases.data(), REEF_HOST));
+        std::vector<std::vector<reef_fe>> scs(8, std::vector<reef_fe>((size_t)n));          // ordinary (pageable) host memory, as a Rust Vec is
+        for (int j = 0; j < 8; ++j) CK(reef_gen_scalars(REEF_PALLAS, 20 + j, 0, 0, (size_t)n, true, scs[j].data(), REEF_HOST));
+        reef_jacobian out;
+        for (int i = 0; i < 4; ++i) mult_pippenger_pallas(&out, bases.data(), (size_t)n, scs[0].data(), true);   // resident from the third call on
+        for (long nt : threads) {
+            std::vector<double> rates, lats;
+            reef_key_cache_timing tm;
+            reef_key_cache_timing_get(nullptr, 1);
+            for (long rep = 0; rep < reps; ++rep) {
+                std::atomic<int> ready{0};
+                std::atomic<bool> go{false};
+                std::vector<double> lat((size_t)nt);
+                std::vector<std::thread> th;
+                for (long t = 0; t < nt; ++t)
+                    th.emplace_back([&, t] {
+                        reef_jacobian o;
+                        mult_pippenger_pallas(&o, bases.data(), (size_t)n, scs[t % 8].data(), true);      // this thread's context exists
+                        ready.fetch_add(1);
+                        while (!go.load()) std::this_thread::yield();
+                        const auto t0 = clk::now();
+                        for (long c = 0; c < calls; ++c) mult_pippenger_pallas(&o, bases.data(), (size_t)n, scs[(t + c) % 8].data(), true);
+                        lat[(size_t)t] = std::chrono::duration<double, std::milli>(clk::now() - t0).count() / calls;
+                    });
+                while (ready.load() < nt) std::this_thread::yield();
+                reef_key_cache_timing_get(nullptr, rep == 0);                                   // the warm-up calls are not the measurement's
+                const auto t0 = clk::now();
+                go.store(true);
+                for (auto &x : th) x.join();
+                const double wall = std::chrono::duration<double>(clk::now() - t0).count();
+                rates.push_back((double)nt * calls * n / wall / 1e6);
+                double s = 0;
+                for (double v : lat) s += v;
+                lats.push_back(s / nt);
+            }
+            reef_key_cache_timing_get(&tm, 0);
+            std::sort(rates.begin(), rates.end());
+            std::sort(lats.begin(), lats.end());
+            const double c = (double)std::max<uint64_t>(1, tm.calls);
+            printf("{\"symbol\": \"mult_pippenger_pallas\", \"points\": %ld, \"threads\": %ld, \"calls_per_thread\": %ld, \"reps\": %ld, \"mpairs_per_s_median\": %.1f, \"mpairs_per_s_min\": %.1f, "
+                   "\"mpairs_per_s_max\": %.1f, \"ms_per_call_median\": %.3f, \"ms_per_call_min\": %.3f, \"ms_per_call_max\": %.3f, \"host_us_per_call\": {\"nominate\": %.1f, \"enqueue\": %.1f, "
+                   "\"confirm\": %.1f, \"wait\": %.1f}}\n",
+                   n, nt, calls, reps, rates[rates.size() / 2], rates.front(), rates.back(), lats[lats.size() / 2], lats.front(), lats.back(), tm.nominate_ns / c / 1e3, tm.enqueue_ns / c / 1e3,
+                   tm.confirm_ns / c / 1e3, tm.wait_ns / c / 1e3);
+            fflush(stdout);
+        }
+    }
+    reef_key_cache_stats st;
+    reef_key_cache_info(&st);
+    printf("{\"key_table\": {\"resident_keys\": %llu, \"resident_mib\": %.0f, \"builds\": %llu, \"clones\": %llu, \"hits\": %llu, \"misspeculated\": %llu}}\n", (unsigned long long)st.resident_keys,
+           st.resident_bytes / 1048576.0, (unsigned long long)st.builds, (unsigned long long)st.clones, (unsigned long long)st.hits, (unsigned long long)st.misspeculated);
+    return 0;
+}
