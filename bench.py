@@ -225,9 +225,10 @@ def _diag(tag):
     print(f"[diag] {tag}: three arguments at once {g['three_arguments_concurrently_ms']} ms", file=sys.stderr, flush=True)
 
 
-SAFA_CAVEAT = ("MSM lengths are PREDICTIONS of Reef's cost model (src/backend/costs.rs restated) for ASSUMED SAFA shapes -- cfg3: the 12-state "
-               "automaton of '.*password.*'; cfg4: a made-up 'DNA motif' of ~128 transitions / 130 states -- not measurements of a Reef run "
-               "(tests/golden/replay_shapes.json `inputs`, `note`)")
+SAFA_CAVEAT = ("MSM lengths are PREDICTIONS of Reef's cost model (src/backend/costs.rs restated: oracle/costs_oracle.py), not measurements of a Reef run; since round 5 the "
+               "automaton behind every config is DERIVED (oracle/safa_shape.py restates SAFA::new for skips and literals; tests/test_safa_shape.py) from a regex with a "
+               "source -- cfg3: '.*password.*' (BASELINE configs[2]): 12 states, 1292 edges; cfg4: tests/scripts/dna.sh:8 re-based to a 16 MiB document: 64 states, 309 edges, "
+               "2 folding steps at -b 32 (tests/golden/replay_shapes.json `inputs`, `hand_count`)")
 
 
 def replay_leg(cfg="cfg3", with_tables=True):

@@ -11,8 +11,10 @@ sizes (padded document: bytes + EOF + EPSILON rounded up to a power of two, src/
 hybrid table 2 * max(table, document), src/backend/r1cs.rs:481-487; Hyrax matrix 2^(l/2) x 2^(l - l/2),
 src/backend/commitment.rs:173-174).
 
-What is an INPUT (Reef's frontend is not restated, and the reference records no SAFA sizes for these documents): the SAFA
-shape and the trace length of each regex, given below with the reasoning.  Change them here and re-run; nothing is typed
+What is an INPUT: the regex, the charset and the flags of each config -- taken from the reference's own scripts and README where it
+holds them (file:line below) -- and the document length BASELINE.json names.  The automaton's shape is no longer typed in (rounds 1-4
+assumed "one edge per literal character"): oracle/safa_shape.py restates SAFA::new for the regex family of those scripts (skips and
+literals) and gives num_states, num_edges, the largest skip offset and the solution length the cost model is fed.  Nothing is typed
 into the harness.
 """
 from __future__ import annotations
@@ -26,30 +28,56 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 from oracle import costs_oracle as K  # noqa: E402
+from oracle import safa_shape as S  # noqa: E402
 
-# ---- inputs: SAFA shape and solver trace per config (assumptions, see the module docstring) ------------------------------
-#  states/edges: one state per literal character of the regex plus the skip/accept states (safa.rs:86-209 builds one
-#  node per derivative); `.*` and `.{n}` are ONE skip edge (safa.rs:600), every literal character is one transition
-#  (safa.rs:364-368).  max_offset = document length for an unbounded skip.  No alternation/lookahead: one branch, stack 1.
+# charsets: src/config.rs:229-233 (ascii: 128 characters), :250-253 (utf8: every Unicode scalar value), :266-268 (dna: ACGT)
+ALPHABETS = {"ascii": (128, None), "dna": (4, "ACGT"), "utf8": (0x110000 - 0x800, None)}
+# The BRCA regexes of tests/scripts/dna.sh address a 10 000-base gene region appended to a long base document: `^.{k}` skips the base
+# and the region's prefix (k = |base| + offset; in the 1 MB documents the tree holds, tests/docs/BRCA1_base1m+primary and
+# BRCA2_base1m+primary, the literals sit at 1 000 000 + 8129 / 5784 / 1970).  For a document of N bytes the same regex is taken with
+# k = N - 10 000 + offset: the only number that changes with the document, as in the reference's own 1 MB / full-size pairs.
+BRCA1_A = "ATGGGCTACAGAAACCGTGCCAAAAGACTTCTACAGAGTGAACCCGAAAATCCTTCCTTG"
+BRCA1_B = ("ATGCTGAAACTTCTCAACCAGAAGAAAGGGCCTTCACAGTGTCCTTTATGTAAGAATGATATAACCAAAAG", "AGCCTACAAGAAAGTACGAGATTTAGTCAACTTGTTGAAGAGCTATTGAAAATCATTTGTGCTTTTCAGCTTGACACAGGTTTGGAGT",
+           "ATGCAAACAGCTATAATTTTGCAAAAAAGGAAAATAACTCTCCTGAACATCTAAAAGATGAAGTTTCTATCATCCAAAGTATGGGCTACAGAAACCGTGCCAAAAGACTTCTACAGAGTGAACCCGAAAATCCTTCCTTG")
+BRCA2_LENS = (428, 182, 188, 171)          # the four literals of dna.sh:12-13 (lengths; any ACGT text of these lengths gives the same automaton shape)
+
+
+def brca(doc_bytes: int, offset: int, literals) -> str:
+    return "^.{%d}" % (doc_bytes - 10000 + offset) + ".*".join(literals)
+
+
 CONFIGS = [
-    dict(name="cfg1_9B_ascii", regex=".*b", doc_bytes=9, alphabet_bits=8, hybrid=False, merkle=False, batch=0,
-         safa=dict(num_states=4, num_edges=4, max_branches=1, max_stack=1), trace=[3]),
-    dict(name="cfg3_1MiB_ascii_password", regex=".*password.*", doc_bytes=1 << 20, alphabet_bits=8, hybrid=False, merkle=False, batch=0,
-         safa=dict(num_states=12, num_edges=12, max_branches=1, max_stack=1), trace=[11]),
-    dict(name="cfg4_16MiB_dna_hybrid_b32", regex="DNA motif, ~128 transitions", doc_bytes=1 << 24, alphabet_bits=3, hybrid=True, merkle=False, batch=32,
-         safa=dict(num_states=130, num_edges=130, max_branches=1, max_stack=1), trace=[128]),
-    dict(name="cfg5_64MiB_utf8_merkle", regex="literal match, ~128 transitions", doc_bytes=1 << 26, alphabet_bits=8, hybrid=False, merkle=True, batch=0,
-         safa=dict(num_states=130, num_edges=130, max_branches=1, max_stack=1), trace=[128]),
+    dict(name="cfg1_9B_ascii", regex=".*b", source="README.md:63 (`reef --input document --re '.*b' ... ascii`, BASELINE configs[0])", charset="ascii",
+         doc_bytes=9, alphabet_bits=8, hybrid=False, merkle=False, batch=0),
+    dict(name="cfg3_1MiB_ascii_password", regex=".*password.*", source="BASELINE.json configs[2] (the reference's password scripts use lookaheads: tests/scripts/password.sh; this "
+         "regex is BASELINE's own)", charset="ascii", doc_bytes=1 << 20, alphabet_bits=8, hybrid=False, merkle=False, batch=0),
+    dict(name="cfg4_16MiB_dna_hybrid_b32", regex=brca(1 << 24, 8129, [BRCA1_A]), source="tests/scripts/dna.sh:8,19 (the regex of :6 on a matching document): `^.{k}` + the 60-base BRCA1 "
+         "literal, k re-based to a 16 MiB document", charset="dna", doc_bytes=1 << 24, alphabet_bits=3, hybrid=True, merkle=False, batch=32,
+         hand_count="nodes: root + 60 literal states + `.*` + empty suffix + sink = 64; edges: skip + complement (2) + sink loop (1) + 60 x (epsilon + ACGT) + `.*` (1) + "
+                    "empty suffix (5) = 309; longest accepting path 62 edges -> solution length 63 -> ceil(63 / 32) = 2 folding steps (tests/test_safa_shape.py)"),
+    dict(name="cfg4b_16MiB_dna_three_literals_hybrid_b32", regex=brca(1 << 24, 5784, BRCA1_B), source="tests/scripts/dna.sh:11,22 (the regex of :7): three BRCA1 literals (71, 88, 140 bases) "
+         "joined by `.*`", charset="dna", doc_bytes=1 << 24, alphabet_bits=3, hybrid=True, merkle=False, batch=32,
+         hand_count="nodes: root + 299 literal states + three `.*` + empty suffix + sink = 305; edges: 2 + 1 + 299 x 5 + 3 + 5 = 1506; solution length 304 -> 10 folding steps"),
+    dict(name="cfg5_64MiB_utf8_merkle", regex=brca(1 << 26, 1970, ["A" * n for n in BRCA2_LENS]), source="tests/scripts/dna.sh:13,24 (the regex of :12): four BRCA2 literals (428, 182, 188, 171 "
+         "bases) joined by `.*`, on a document read with the utf8 charset as BASELINE configs[4] names it (--merkle excludes projections and --hybrid: r1cs.rs:511-512)",
+         charset="utf8", doc_bytes=1 << 26, alphabet_bits=8, hybrid=False, merkle=True, batch=0),
 ]
+
+
+def safa_of(cfg: dict) -> S.Shape:
+    size, chars = ALPHABETS[cfg["charset"]]
+    return S.shape(cfg["regex"], size, chars)
 
 
 def evaluate(cfg: dict) -> dict:
     udoc_len = K.next_power_of_two(cfg["doc_bytes"] + 2)                 # + EOF + EPSILON, zero-padded (framework.rs:997-1008)
     doc_log = K.logmn(udoc_len)
-    safa = K.SafaShape(max_offset=udoc_len, **cfg["safa"])
+    sh = safa_of(cfg)
+    trace = list(sh.path_lens)                                           # `final_paths`: what NFA::new hands the cost model (r1cs.rs:335, :496-506)
+    safa = K.SafaShape(num_states=sh.num_states, num_edges=sh.num_edges, max_offset=sh.max_offsets, max_branches=1, max_stack=1)
     table = K.next_power_of_two(safa.num_edges)
     hybrid_len = 2 * K.next_power_of_two(max(table, udoc_len)) if cfg["hybrid"] else None   # r1cs.rs:481-487
-    batch = cfg["batch"] or max(2, K.opt_cost_model_select(safa, udoc_len, cfg["hybrid"], hybrid_len, False, cfg["trace"]))   # r1cs.rs:489-513 (> 1)
+    batch = cfg["batch"] or max(2, K.opt_cost_model_select(safa, udoc_len, cfg["hybrid"], hybrid_len, False, trace))   # r1cs.rs:489-513 (> 1)
     if cfg["merkle"]:
         # costs.rs has no Merkle term: the document lookups of nl_doc are replaced by b Merkle paths of log2 N Poseidon
         # hashes each (nova.rs:392-547).  Extrapolated with the model's own sponge-block constant (288, costs.rs:132).
@@ -57,14 +85,15 @@ def evaluate(cfg: dict) -> dict:
                 + K.stack_circuit(safa.num_states, udoc_len, safa.max_branches, safa.max_stack) + batch * doc_log * 288)
     else:
         step = K.full_round_cost_model(safa, batch, udoc_len, cfg["hybrid"], hybrid_len, False)
-    steps = K.n_foldings(cfg["trace"], batch)
+    steps = K.n_foldings(trace, batch)
     primary = K.V1 + step
     table_log = K.logmn(hybrid_len) if cfg["hybrid"] else doc_log
     out = dict(name=cfg["name"], w1=primary, c1=primary, w2=K.V2, c2=K.V2, steps=steps, batch=batch, step_circuit_constraints=step,
                hyrax_row=0 if cfg["merkle"] else 1 << (doc_log - doc_log // 2), doc_log=0 if cfg["merkle"] else doc_log,
                symbol_bits=cfg["alphabet_bits"], table_log=0 if cfg["merkle"] else table_log, lookups=2 * batch if cfg["hybrid"] else batch,
                merkle_log=doc_log if cfg["merkle"] else 0,
-               folded_cost=K.get_folded_cost(step, cfg["trace"], batch))
+               folded_cost=K.get_folded_cost(step, trace, batch),
+               safa_states=sh.num_states, safa_edges=sh.num_edges, safa_max_offsets=sh.max_offsets, solution_lens=trace)
     return out
 
 
@@ -73,8 +102,9 @@ def main() -> None:
     doc = {
         "generated_by": "oracle/gen_replay_shapes.py (oracle/costs_oracle.py restates src/backend/costs.rs of eniac/Reef)",
         "constants": {"V1": K.V1, "V2": K.V2},
-        "inputs": [{k: v for k, v in c.items()} for c in CONFIGS],
-        "note": "MSM lengths are PREDICTIONS of Reef's cost model for assumed SAFA shapes (inputs), not measurements of a Reef run",
+        "inputs": [{k: (v if k != "regex" or len(v) < 200 else v[:120] + "..." + v[-40:]) for k, v in c.items()} for c in CONFIGS],
+        "note": "MSM lengths are PREDICTIONS of Reef's cost model (src/backend/costs.rs restated) for automata DERIVED from the regexes above by "
+                "oracle/safa_shape.py (SAFA::new restated for skips and literals), not measurements of a Reef run",
         "shapes": shapes,
     }
     path = os.path.join(ROOT, "tests", "golden", "replay_shapes.json")

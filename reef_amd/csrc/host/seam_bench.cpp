@@ -5,7 +5,7 @@
 // the calls spent their host time (reef_key_cache_timing_get: nominate / enqueue incl. the staging of the pageable scalars / confirm
 // the key's bytes / wait).  One line of JSON per (size, threads).
 //
-// usage: seam_bench [sizes=24918,65536] [threads=1,4,8] [calls=500] [reps=5]
+// usage: seam_bench [sizes=27790,65536] [threads=1,4,8] [calls=500] [reps=5]
 #include <algorithm>
 #include <atomic>
 #include <chrono>
@@ -37,7 +37,7 @@ static std::vector<long> list_of(const char *s) {
 using clk = std::chrono::steady_clock;
 
 int main(int argc, char **argv) {
-    std::vector<long> sizes = {3000, 24918, 65536, 262144}, threads = {1, 4, 8};
+    std::vector<long> sizes = {3000, 27790, 65536, 262144}, threads = {1, 4, 8};
     long calls = 500, reps = 5;
     for (int i = 1; i < argc; ++i) {
         if (!strncmp(argv[i], "sizes=", 6)) sizes = list_of(argv[i] + 6);

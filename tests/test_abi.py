@@ -137,4 +137,4 @@ def test_replay_library_exports_its_entry_point_and_fails_loudly_without_gpu():
         replay.run("cfg3")
     assert "failed with 3" in str(e.value)
     shapes = replay.shapes()
-    assert set(n.split("_")[0] for n in shapes) == {"cfg1", "cfg3", "cfg4", "cfg5"}
+    assert set(n.split("_")[0] for n in shapes) == {"cfg1", "cfg3", "cfg4", "cfg4b", "cfg5"}

@@ -61,3 +61,9 @@ def test_committed_shapes_are_what_the_model_gives():
     assert doc["shapes"] == [G.evaluate(c) for c in G.CONFIGS]
     for s in doc["shapes"]:
         assert s["w1"] == K.V1 + s["step_circuit_constraints"] and s["w2"] == K.V2 and s["steps"] >= 1 and s["batch"] > 1   # r1cs.rs:513
+    # every automaton is DERIVED (oracle/safa_shape.py, tests/test_safa_shape.py) from a regex with a source; nothing about it is typed in
+    by_name = {s["name"]: s for s in doc["shapes"]}
+    assert all("safa" not in c and c["source"] and c["regex"] for c in doc["inputs"])
+    cfg4 = by_name["cfg4_16MiB_dna_hybrid_b32"]
+    assert (cfg4["safa_states"], cfg4["safa_edges"], cfg4["solution_lens"], cfg4["steps"]) == (64, 309, [63], 2)     # ceil(63 / 32) folding steps
+    assert by_name["cfg4b_16MiB_dna_three_literals_hybrid_b32"]["steps"] == 10

@@ -9,7 +9,7 @@ import numpy as np
 import pytest
 
 pytestmark = pytest.mark.gpu
-SIZES = (128, 3000, 24918, 1 << 16)          # below the cache threshold, small, cfg3's W key length (replay_shapes.json), Reef's 2^16
+SIZES = (128, 3000, 27790, 1 << 16)          # below the cache threshold, small, cfg3's W key length (replay_shapes.json), Reef's 2^16
 
 
 def cache_info():
@@ -145,7 +145,7 @@ def test_msm_multi_matches_the_calls_one_by_one(gpu_lib, cref):
     keys = {cid: cref.gen_bases_ap(cid, 800 + cid, 3, 1 << 15) for cid in (0, 1)}
     ctx = {cid: msm.MsmContext(cid, keys[cid], bucket_groups=1) for cid in (0, 1)}
     clones = {cid: ctx[cid].clone() for cid in (0, 1)}
-    lens = [(1, 11376), (0, 24918), (0, 24917), (1, 3)]
+    lens = [(1, 11376), (0, 27790), (0, 27789), (1, 3)]
     scs = [cref.gen_scalars(cid, 70 + j, n, kind=j % 2) for j, (cid, n) in enumerate(lens)]
     want = [cref.compress(cid, cref.msm_pippenger(cid, keys[cid][:n].copy(), sc, threads=4)) for (cid, n), sc in zip(lens, scs)]
     order = [ctx[1], ctx[0], clones[0], clones[1]]

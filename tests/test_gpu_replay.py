@@ -37,17 +37,17 @@ def test_replay_checks_every_commitment(cfg, tables, gpu_lib):
 
 def test_replay_cfg5_merkle_document(gpu_lib):
     """BASELINE configs[4]: the 64 MiB --merkle document.  No Hyrax commitment and no consistency argument; the Merkle gadget
-    inflates the step circuit (a 362 994-point Pallas key, 2^19 pre-shifted points), the document is committed by the Poseidon
+    inflates the step circuit (122 lookups x 27 levels per step: a 1 022 173-point Pallas key, 2^20 pre-shifted points), the document is committed by the Poseidon
     tree over 2^27 symbols (row N4, stand-in constants: timing and plumbing; parity of the tree is tests/test_gpu_merkle.py)."""
     from reef_amd import replay
     line = replay.run("cfg5", nofold=True, tables=False)
     shape = next(s for name, s in replay.shapes().items() if "cfg5" in name)
     assert (line["w1"], line["c1"], line["w2"], line["c2"]) == (shape["w1"], shape["c1"], shape["w2"], shape["c2"])
-    assert line["key_pallas"] == 1 << 19 and line["w1"] > 1 << 18
+    assert line["key_pallas"] == 1 << 20 and line["w1"] > 1 << 19
     assert line["commitments_checked_against_dlog"] == _expected_checks(shape)
     assert line["consistency_rounds"] == 0 and line["consistency_ipa_ms"] == 0          # --merkle has no Hyrax argument
     assert line["commit_merkle_log"] == 27 and line["commit_merkle_ms"] > 0
-    assert line["ipa_pallas_rounds"] == 19 and line["total_prove_msm_ms"] > 0
+    assert line["ipa_pallas_rounds"] == 20 and line["total_prove_msm_ms"] > 0
 
 
 def test_replay_with_generator_folds(gpu_lib):

@@ -47,7 +47,7 @@ if not args.threads:
     sys.exit(0)
 
 counts = [int(x) for x in args.threads.split(",")]
-for n in [1 << x for x in (args.logn or [])] or [3000, 24918, 1 << 16, 1 << 18]:
+for n in [1 << x for x in (args.logn or [])] or [3000, 27790, 1 << 16, 1 << 18]:
     bases = msm.gen_bases("pallas", 11 + n % 97, 3, n)
     scs = [msm.gen_scalars("pallas", 20 + j, n) for j in range(8)]
     for _ in range(3):                                 # warm: the resident copy exists from the third call on
