@@ -142,7 +142,8 @@ reef_status reef_msm_ctx_attach(reef_msm_ctx *ctx, reef_msm_ctx *src);
 void reef_msm_ctx_destroy(reef_msm_ctx *ctx);
 /* Block until everything enqueued on the ctx's stream has finished. */
 reef_status reef_msm_ctx_sync(reef_msm_ctx *ctx);
-/* The ctx's hipStream_t (as void*), e.g. to order work of a torch/RCCL stream after it. */
+/* The ctx's hipStream_t (as void*), e.g. to order work of a torch/RCCL stream after it: from here on the ctx stays on this stream of the
+ * library's pool.  NULL on failure (no stream could be had; reef_last_error() says why) -- never a stand-in for the default stream. */
 void *reef_msm_ctx_stream(reef_msm_ctx *ctx);
 
 /* K1: out = sum_{i<n} scalars[i] * bases[i], n <= key length.
@@ -379,13 +380,12 @@ reef_status reef_memcpy(void *dst, const void *src, size_t bytes, int dst_loc, i
 const char *reef_last_error(void);                     /* thread-local message of the last failure */
 const char *reef_version(void);
 uint32_t reef_abi_version(void);                       /* REEF_ABI_VERSION of the library that was loaded */
-/* Process-wide runtime settings, for embedders that want them explicit.  The HIP runtime maps a process's streams onto
- * GPU_MAX_HW_QUEUES hardware queues (4 unless set) and streams that share a queue run in turn; concurrent callers of this
- * library (the three arguments of the final SNARK, rayon workers: src/backend/framework.rs:695-721) want 8.  The variable is
- * read at the process's FIRST HIP call, so this must run before it.  By default (opt-out) the library puts 8 into the
- * environment when it is loaded unless the variable is already set or REEF_MSM_HW_QUEUES=0; this call makes the choice
- * explicit: hw_queues > 0 asks for that many, < 0 withdraws the library's own setting, 0 changes nothing.  A value the user
- * exported is never overwritten.  info (may be NULL) reports what the environment holds and who put it there. */
+/* Process-wide runtime settings.  The HIP runtime maps a process's streams onto GPU_MAX_HW_QUEUES hardware queues (4 unless set) and
+ * streams that share a queue run in turn; concurrent callers of this library (the three arguments of the final SNARK, rayon workers:
+ * src/backend/framework.rs:695-721) want 8.  The variable is read at the process's FIRST HIP call, so this must run before it.
+ * OPT-IN (ABI 5): the library touches the environment only when asked -- hw_queues > 0 here, or REEF_MSM_HW_QUEUES=<n> exported when
+ * the library is loaded; hw_queues < 0 withdraws a value the library set, 0 changes nothing.  A value the user exported as
+ * GPU_MAX_HW_QUEUES is never overwritten.  info (may be NULL) reports what the environment holds and who put it there. */
 typedef struct {
     int32_t hw_queues;
     uint32_t reserved[7];

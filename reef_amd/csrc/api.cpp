@@ -35,9 +35,10 @@ void set_error(const char *fmt, ...) {
 // the final SNARK issued at once that is more than four, and their latency-bound rounds queue up behind each
 // other -- 8.3 ms against 6.4 ms with eight queues for cfg3, 4 threads of IPA rounds 1.95x against 2.55x one thread
 // (tools/time_concurrent_ipa.py).  The variable is read when the runtime initialises, i.e. at the process's first HIP call.
-// Two ways in: an embedder calls reef_runtime_init() before its first HIP call (explicit, reported back), or -- the opt-out
-// default -- the library asks for 8 when it is loaded unless the user has set the variable (REEF_MSM_HW_QUEUES=<n> asks for n,
-// =0 leaves the runtime alone).  Either way a value the user exported wins, and REEF_MSM_LOG=1 says on stderr what was done.
+// OPT-IN since round 5 (rounds 3-4 put 8 into the environment whenever the library was loaded): an embedder
+// calls reef_runtime_init({hw_queues = 8}) before its first HIP call (explicit, reported back), or exports REEF_MSM_HW_QUEUES=<n>
+// -- then the library asks for n when it is loaded.  Without either the runtime is left alone.  A value the user exported as
+// GPU_MAX_HW_QUEUES always wins, and the library says once on stderr when it has put the variable there.
 namespace {
 std::atomic<int> g_hw_queues_asked{0};     // what this library put into the environment (0: nothing)
 static int ask_hw_queues(int n) {
@@ -47,15 +48,16 @@ static int ask_hw_queues(int n) {
     snprintf(buf, sizeof buf, "%d", n);
     setenv("GPU_MAX_HW_QUEUES", buf, 0);
     g_hw_queues_asked.store(n);
-    if (const char *l = getenv("REEF_MSM_LOG"))
-        if (atoi(l) > 0) fprintf(stderr, "libreef_msm: GPU_MAX_HW_QUEUES=%d set for this process (REEF_MSM_HW_QUEUES=0 or reef_runtime_init opts out)\n", n);
+    static std::atomic<bool> said{false};
+    const char *l = getenv("REEF_MSM_LOG");
+    if (!said.exchange(true) && !(l && l[0] == '0' && l[1] == 0))
+        fprintf(stderr, "libreef_msm: GPU_MAX_HW_QUEUES=%d set for this process on request (reef_runtime_init / REEF_MSM_HW_QUEUES; REEF_MSM_LOG=0 silences this line)\n", n);
     return n;
 }
 struct HwQueues {
     HwQueues() {
         const char *o = getenv("REEF_MSM_HW_QUEUES");
-        if (o && o[0] == '0' && o[1] == 0) return;
-        ask_hw_queues((o && *o) ? atoi(o) : 8);
+        if (o && *o && atoi(o) > 0) ask_hw_queues(atoi(o));   // only on the user's explicit request
     }
 } g_hw_queues;
 }  // namespace
@@ -126,7 +128,13 @@ template <class F> static reef_status guarded(F &&f) {
 extern "C" {
 
 const char *reef_last_error(void) { return g_err; }
-const char *reef_version(void) { return "reef_msm 0.4 (gfx950)"; }
+const char *reef_version(void) {
+#ifdef REEF_EXPERIMENT
+    return "reef_msm 0.5 (gfx950; +experiment: the A/B switches of common.h are compiled in)";
+#else
+    return "reef_msm 0.5 (gfx950; release)";
+#endif
+}
 uint32_t reef_abi_version(void) { return REEF_ABI_VERSION; }
 reef_status reef_runtime_init(const reef_runtime_opts *opts, reef_runtime_info *info) {
     if (opts && opts->hw_queues > 0) {

@@ -17,6 +17,25 @@ def test_library_present_and_loads():
     assert lib.reef_abi_version() == header == _ffi.ABI_VERSION          # header, binding and binary agree
 
 
+def test_in_tree_build_is_the_experiment_build_and_says_so():
+    """The A/B switches (common.h: exp_env) exist only in builds with -DREEF_EXPERIMENT -- the in-tree build the tests and tools load;
+    `make -C reef_amd/csrc release` compiles them out.  The version string tells the two apart."""
+    assert b"+experiment" in _ffi.load().reef_version()
+    mk = open(os.path.join(_ffi.CSRC, "Makefile")).read()
+    assert "EXPERIMENT ?= 1" in mk and "release:" in mk and "-DREEF_EXPERIMENT" in mk
+    common = open(os.path.join(_ffi.CSRC, "common.h")).read()
+    import glob
+    import re
+    supported = set(re.findall(r"REEF_[A-Z0-9_]+", common.split("inline const char *exp_env")[0].split("Environment switches come in two kinds")[1]))
+    supported -= {"REEF_EXPERIMENT"}
+    read = set()
+    for f in glob.glob(os.path.join(_ffi.CSRC, "*.inc")) + glob.glob(os.path.join(_ffi.CSRC, "*.cpp")) + glob.glob(os.path.join(_ffi.CSRC, "*.h")):
+        read |= set(re.findall(r'[^_a-z]getenv\("(REEF_[A-Z0-9_]+)"\)', open(f).read()))
+    assert read <= supported | {"REEF_MSM_KEY_CACHE_MB", "REEF_MSM_KEY_HOST_MB"}, read - supported      # every plain getenv is a documented switch
+    doc = open(os.path.join(os.path.dirname(_ffi.HEADER), "..", "INTEGRATION.md")).read()
+    assert all(name in doc for name in supported), [n for n in supported if n not in doc]
+
+
 def test_runtime_init_reports_who_set_the_hardware_queues():
     """reef_runtime_init makes the GPU_MAX_HW_QUEUES choice explicit: it never overwrites a value the user exported and
     reports what the environment holds; pure host logic, no HIP call."""
