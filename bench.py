@@ -823,12 +823,39 @@ def main():
                 strong.update(independent_units_legs(a, rank, world, dist))
             except Exception as e:
                 strong["independent_units_error"] = str(e)
+        # (round 5) what ONE process gets from the same N devices through the library's device groups (reef_msm_group_*: the form a Rust prover can
+        # call; Reef is one process, src/backend/main.rs:82) -- a child of rank 0 with no launcher variables runs `bench.py --gpus N --single-process`
+        # over every visible device while the other ranks wait; a child, so that a first-time failure of the untested cross-device calls (peer
+        # copies, cross-device event waits) costs this field, not the line.
+        if isinstance(strong, dict) and "error" not in strong and os.environ.get("REEF_BENCH_SINGLE", "1") != "0":
+            if rank == 0:
+                try:
+                    import subprocess
+                    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "GROUP_RANK", "ROLE_RANK",
+                                                                          "LOCAL_WORLD_SIZE", "ROLE_WORLD_SIZE", "TORCHELASTIC_RUN_ID") and not k.startswith("TORCHELASTIC")}
+                    child = subprocess.run([sys.executable, os.path.abspath(__file__), "--gpus", str(a.gpus), "--single-process", "--logn", str(a.logn), "--steps", "2", "--warmup", "1",
+                                            "--msms-per-step", "12", "--curve", a.curve], capture_output=True, text=True, timeout=240, env=env)
+                    lines = [ln for ln in child.stdout.splitlines() if ln.startswith("{")]
+                    if child.returncode == 0 and lines:
+                        cl = json.loads(lines[-1])
+                        cc = cl["config"]
+                        strong["single_process"] = {"value": cl["value"], "ms_per_msm": cc["ms_per_msm"], "host_scalars_ms_per_msm": cc["host_scalars_ms_per_msm"],
+                                                    "devices": cc["devices"], "distinct_devices": cc["distinct_devices"], "exchange": cc["exchange"], "peer_members": cc["peer_members"],
+                                                    "check": cc["check"], "strong_scaling": cc["strong_scaling"], "devices_note": cc["devices_note"],
+                                                    "note": "`bench.py --gpus N --single-process` run by rank 0 as a child while the other ranks wait: one process, N members, "
+                                                            "the library's own exchange (no torch.distributed); value = pairs/s of one N x 2^logn-point MSM per call, weak scaling by points"}
+                    else:
+                        strong["single_process"] = {"error": f"child exited with {child.returncode}: {child.stderr[-400:]}"}
+                except Exception as e:
+                    strong["single_process"] = {"error": str(e)}
+            dist.barrier()
 
     # ---- after the timed region (none of this is `value`) ------------------------------------------------
     # (1) the accumulation kernel with ONE MSM in flight: with several MSMs sharing the chip a launch is stretched by
     #     its neighbours, so the per-launch duration above understates the kernel
     single = None
     host_ms = None
+    host_pageable = None
     if not multi:
         reps = max(3, min(10, a.steps * MPS))
         for _ in range(reps):
@@ -848,18 +875,23 @@ def main():
             hthreads = max(nctx, 6)
             hctx = list(ctxs) + [ctxs[0].clone() for _ in range(hthreads - nctx)]
             outs = [np.zeros(12, dtype=np.uint64) for _ in hctx]
-            per_thread = max(2, min(a.steps * MPS, 24) // hthreads + 1)
+            per_thread = max(8, min(a.steps * MPS, 48) // hthreads + 1)
 
-            def host_worker(j):               # one caller thread per resident-key clone, as nova's rayon workers would be
-                for _ in range(per_thread):
-                    hctx[j].msm(hs, n, out=outs[j])
-            for j in range(hthreads):         # warm-up (staging buffers)
-                hctx[j].msm(hs, n, out=outs[j])
-            th = [threading.Thread(target=host_worker, args=(j,)) for j in range(hthreads)]
-            t1 = time.perf_counter()
-            [x.start() for x in th]
-            [x.join() for x in th]
-            host_ms = (time.perf_counter() - t1) / (per_thread * hthreads) * 1e3
+            def run_host(buf, nthreads):      # one caller thread per resident-key clone, as nova's rayon workers would be; -> ms per MSM
+                def host_worker(j):
+                    for _ in range(per_thread):
+                        hctx[j].msm(buf, n, out=outs[j])
+                for j in range(nthreads):     # warm-up (staging buffers)
+                    hctx[j].msm(buf, n, out=outs[j])
+                th = [threading.Thread(target=host_worker, args=(j,)) for j in range(nthreads)]
+                t1 = time.perf_counter()
+                [x.start() for x in th]
+                [x.join() for x in th]
+                return (time.perf_counter() - t1) / (per_thread * nthreads) * 1e3
+            host_ms = run_host(hs, hthreads)
+            # the same from PAGEABLE memory -- what a Rust Vec is: the runtime stages or pins it per call
+            hp = np.array(hs, copy=True)
+            host_pageable = {"one_caller": run_host(hp, 1), "six_callers": run_host(hp, hthreads)}
             for c in hctx[nctx:]:
                 c.close()
             if not a.no_check and msm.compress(a.curve, outs[0]) != msm.compress(a.curve, final_result.view(np.uint64)):
@@ -917,7 +949,7 @@ def main():
         # one is refused rather than quoted (no fall-back to an older round's file)
         traffic, traffic_src = None, None
         from reef_amd import _ffi as _f
-        prof_name = "r04_pmc_traffic.json"
+        prof_name = "r05_pmc_traffic.json"
         try:
             prof = json.load(open(os.path.join(ROOT, "profiles", prof_name)))
             pc = prof["config"]
@@ -944,8 +976,10 @@ def main():
                                    f"resident key, device-resident scalars (BASELINE.json configs[1]); a step = a batch of {MPS * B} such MSMs",
                        "scalars": "device-resident (generated on the GPU before the timed region; no PCIe traffic inside it)",
                        "host_scalars_ms_per_msm": host_ms,
-                       "host_scalars_note": "same MSMs with the scalars in pinned host memory and the result returned to the host, six caller "
-                                            "threads each on its own clone of the resident key; PCIe-inclusive, measured after the timed region, never `value`",
+                       "host_scalars_pageable_ms_per_msm": host_pageable,
+                       "host_scalars_note": "same MSMs with the scalars in host memory and the result returned to the host, caller threads each on its own clone of "
+                                            "the resident key; PCIe-inclusive, measured after the timed region, never `value`.  host_scalars_ms_per_msm: PINNED memory, six "
+                                            "callers; host_scalars_pageable_ms_per_msm: ordinary pageable memory (what a Rust Vec is), one caller and six",
                        "points_per_gpu": n, "total_points": n * (1 if by_windows else a.gpus), "window_bits": plan["window_bits"],
                        "windows": plan["windows"], "bucket_groups": plan["bucket_groups"], "tables": plan["tables"],
                        "streams": nctx, "msms_per_step": MPS * B, "ms_per_msm": elapsed / (a.steps * MPS * B) * 1e3, "sharding": ("windows (w = rank mod N)" if by_windows else "points") if a.gpus > 1 else "none",

@@ -181,6 +181,20 @@ def kernel_sources_sha16() -> str:
     return h.hexdigest()[:16]
 
 
+def library_sources_sha16() -> str:
+    """Fingerprint of EVERYTHING libreef_msm.so is compiled from (kernels, engines, the C ABI, the Makefile): what a soak or a stress run
+    vouches for is this build and no other (profiles/r05_soak.txt records it; tests/test_profiles_fresh.py compares)."""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    names = sorted(glob.glob(os.path.join(CSRC, "*.inc")) + glob.glob(os.path.join(CSRC, "*.h")) + glob.glob(os.path.join(CSRC, "*.hip")) +
+                   glob.glob(os.path.join(CSRC, "*.cpp")) + [os.path.join(CSRC, "Makefile"), HEADER])
+    for name in names:
+        with open(name, "rb") as f:
+            h.update(os.path.basename(name).encode() + b"\0" + f.read())
+    return h.hexdigest()[:16]
+
+
 def declared_symbols() -> list[str]:
     """Function names declared in include/reef_msm.h (used by the ABI export test)."""
     import re

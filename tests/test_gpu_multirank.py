@@ -57,6 +57,9 @@ def test_bench_with_two_ranks(sharding, logn, gpu_lib):
         fs, scs = ss["final_snark"], ss["sumcheck"]            # round 4: whole units over the ranks
         assert fs["owner"] == [0, 1, 1] and fs["check"] == "same-points" and fs["ms"] > 0 and fs["one_gpu_one_after_the_other_ms"] > 0
         assert scs["ell"] == 26 and scs["entries_per_rank"] == 1 << 25 and scs["check"] == "sumcheck-identity-ok" and scs["ms_per_step"] > 0
+        sp = ss["single_process"]                              # round 5: the same devices driven by ONE process through reef_msm_group_* (a child of rank 0)
+        assert sp["check"] == "dlog-ok" and sp["devices"] == [0, 0] and sp["exchange"].startswith("peer") and sp["value"] > 0
+        assert sp["strong_scaling"]["windows_ms_per_step"] > 0 and sp["strong_scaling"]["points_ms_per_step"] > 0
         assert set(ss["speedup_vs_1"]) == {"windows", "points"} and ss["one_gpu_ms_per_msm"] == pytest.approx(cfg["ms_per_msm"]) and cfg["msms_per_step"] == 256 \
             and line["ms_per_step"] == pytest.approx(256 * cfg["ms_per_msm"])
     else:

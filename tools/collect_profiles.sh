@@ -1,6 +1,6 @@
 #!/bin/bash
 # On the MI355X box: everything profiles/ holds for a round.  usage: tools/collect_profiles.sh OUTDIR [rNN]
-out=$(realpath -m $1); R=${2:-r04}; export REEF_ROUND=$R
+out=$(realpath -m $1); R=${2:-r05}; export REEF_ROUND=$R
 mkdir -p $out; export TMPDIR=/tmp; root=$GRAFT_REPO_ROOT
 python $root/bench.py --steps 20 --warmup 5 > $out/${R}_bench.json 2> $out/${R}_bench.err
 # per-kernel time of the same timed region: the legs that run other sizes through the same kernels after it (replay, CPU) are left out
@@ -61,3 +61,29 @@ for m in fresh contexts-alive threads-leftover torch-first; do python $root/tool
  echo "# REEF_SC_SPLIT_MAX=0 REEF_SC_ITEMS=1 REEF_SC_FLOOR=1: and a pair per thread in the mid-sized rounds (the round 3 grid)"; REEF_SC_SPLIT_MAX=0 REEF_SC_ITEMS=1 REEF_SC_FLOOR=1 python $root/tools/step_breakdown.py 21) > $out/${R}_small_rounds_ab.txt 2>&1
 (cd /tmp; for L in 21 26; do rm -rf /tmp/tl$L; rocprofv3 --kernel-trace --output-format csv -d /tmp/tl$L -- python $root/tools/step_breakdown.py $L > /dev/null 2>&1; echo "## ell = $L: kernels of the last step (us)"; python $root/tools/step_timeline.py /tmp/tl$L/*/*kernel_trace.csv; done) > $out/${R}_step_timeline.txt 2>&1
 (export CHUNKS=0,5,8,10,16; python $root/tools/sweep_chunk.py 15 13; python $root/tools/sweep_chunk.py 16 15) > $out/${R}_chunk_sweep.txt 2>&1
+# round 5 additions
+sha=$(cd $root && python -c "from reef_amd import _ffi; print(_ffi.library_sources_sha16())")
+$root/reef_amd/_lib/seam_bench > $out/${R}_stateless_concurrent.txt 2>&1
+python $root/tools/time_stateless.py --threads 1,4,8 > $out/${R}_stateless_concurrent_python.txt 2>&1
+python $root/tools/time_group.py > $out/${R}_group_timing.txt 2>&1
+(for m in 2 8; do python $root/bench.py --gpus $m --single-process --steps 3 --warmup 1 --msms-per-step 24 2>/dev/null; done) > $out/${R}_bench_single_process.jsonl
+(for m in 3 8; do $root/reef_amd/_lib/reef_replay cfg4 nofold devices=$m 2>/dev/null; done; $root/reef_amd/_lib/reef_replay cfg4b nofold 2>/dev/null) > $out/${R}_replay_devices.jsonl
+$root/reef_amd/_lib/affine_probe > $out/${R}_affine_probe.txt 2>&1
+bash $root/tools/sweep_sc_mid.sh $out/${R}_sc_mid_sweep.txt
+python $root/tools/pmc_sc_step.py 26 $out/${R}_pmc_sc_step_26.json > /dev/null 2>&1; python $root/tools/pmc_sc_step.py 21 $out/${R}_pmc_sc_step_21.json > /dev/null 2>&1
+# the one-launch sum-check rounds under load, ten times the GPU suite's count, all three orderings of the hand-over (sumcheck_kernels.inc: SC_ORDER_*)
+(echo "# reef_amd/_lib/sc_stress <ell> <steps> load: one folding step repeated under k_accum0 + streaming load, every coefficient triple against the two-launch form; library sources $sha"
+ run() { env REEF_SC_FENCE=$1 $3 $root/reef_amd/_lib/sc_stress $2 $4 load; }
+ for f in 0 1 2; do n=$([ $f = 0 ] && echo 20000 || echo 2000)
+   run $f 12 "REEF_SC_BLOCKS=2 REEF_SC_ITEMS=1 REEF_SC_SPLIT_MAX=0" $n
+   run $f 18 "REEF_SC_BLOCKS=3 REEF_SC_ITEMS=1 REEF_SC_SPLIT_MAX=0" $n
+   run $f 16 "REEF_SC_BLOCKS=16 REEF_SC_ITEMS=1 REEF_SC_SPLIT_MAX=0" $n
+   run $f 18 "REEF_SC_BLOCKS=64 REEF_SC_ITEMS=1 REEF_SC_SPLIT_MAX=0" $n
+   run $f 20 "REEF_SC_BLOCKS=2048 REEF_SC_ITEMS=1 REEF_SC_SPLIT_MAX=0 REEF_SC_ONE_LAUNCH_MAX=8192" $((n / 2))
+   run $f 17 "" $n
+   run $f 18 "REEF_SC_SPLIT_BLOCKS=1024 REEF_SC_SPLIT_MAX=65536" $((n / 2))
+   run $f 16 "REEF_SC_RANK1_MIN_POW=1" $((n / 2))
+ done) > $out/${R}_sc_stress.txt 2>&1
+# the soak LAST, on the build everything above was measured on: it records the fingerprint of the library's sources, and
+# tests/test_profiles_fresh.py refuses a soak of other sources
+python $root/tools/soak.py ${SOAK_SECONDS:-600} 5 > $out/${R}_soak.txt 2>&1

@@ -18,7 +18,7 @@ t_end = time.time() + budget
 done = 0
 while time.time() < t_end:
     cid = int(rng.integers(0, 2))
-    shape = rng.integers(0, 11)
+    shape = rng.integers(0, 13)
     if shape == 0:      # single MSM, any size
         n = int(2 ** rng.uniform(0, 21.2 if os.environ.get("SOAK_BIG") else 18.5))
         kind = int(rng.integers(0, 3))
@@ -44,6 +44,29 @@ while time.time() < t_end:
                     parts.append(ctx.msm(sc[:m].copy()))
                 ctx.set_window_split(0, 1)
                 assert msm.compress(cid, msm.sum_points(cid, np.stack(parts))) == want, ("split", cid, n, m, world)
+    elif shape in (11, 12):   # device groups (one process, several members: ordinals repeat beyond the box's devices): MSMs and rows
+        n = int(2 ** rng.uniform(0, 17))
+        members = int(rng.integers(1, 9))
+        devs = [int(i) % msm.device_count() for i in range(members)]
+        bases = R.gen_bases_ap(cid, int(rng.integers(1, 1 << 30)), int(rng.integers(1, 1000)), n)
+        if n > 8 and rng.random() < 0.3:
+            bases[rng.integers(0, n, size=2)] = 0
+        sc = R.gen_scalars(cid, int(rng.integers(1, 1 << 30)), n, kind=int(rng.integers(0, 2)))
+        split = int(rng.integers(0, 2))
+        with msm.MsmGroup(cid, bases, devs, split=split, exchange=int(rng.choice([1, 2])), bucket_groups=int(rng.choice([0, 1, 1]))) as g:
+            m = int(rng.integers(0, n + 1)) if rng.random() < 0.3 else n
+            want = R.compress(cid, R.msm_pippenger(cid, bases[:m].copy(), sc[:m].copy(), threads=16)) if m else bytes(32)
+            buf = sc[:m].copy() if m else np.zeros((0, 4), np.uint64)
+            assert msm.compress(cid, g.msm(buf, m)) == want, ("group", cid, n, m, members, split)
+            if split == 0 and rng.random() < 0.5:
+                rows = int(rng.integers(1, 40))
+                row_len = int(rng.integers(1, min(n, 600) + 1))
+                bound = int(rng.choice([7, 131, 0]))
+                rsc = R.gen_scalars(cid, int(rng.integers(1, 1 << 30)), rows * row_len, kind=2 if bound else 0, small_bound=bound)
+                bl = R.gen_scalars(cid, int(rng.integers(1, 1 << 30)), rows)
+                h = R.gen_bases_ap(cid, 0xB11D, 1, 1)[0].copy()
+                wr = R.compress(cid, R.row_msm(cid, bases[:row_len].copy(), rsc, rows, row_len, h=h, blinds=bl, threads=16))
+                assert msm.compress(cid, g.msm_rows(rsc, rows, row_len, blinds=bl, h=h)) == wr, ("group-rows", cid, rows, row_len, members)
     elif shape == 7:    # key derivation (stand-in parameter sets)
         name = "pallas" if cid == 0 else "vesta"
         k = KO.standin_params(name, int(rng.integers(0, 3)), bool(rng.integers(0, 2)))
@@ -181,4 +204,5 @@ while time.time() < t_end:
                     assert msm.compress(cid, d_out.to_host((rows, 12))) == want2, ("rows-device", cid, rows, row_len, bound)
                 assert msm.compress(cid, ctx.msm_rows(sc, rows, row_len, blinds=bl, h=h)) == want, ("rows-host-again", cid, rows, row_len)
     done += 1
-print(f"soak ok: {done} random cases in {budget:.0f} s")
+from reef_amd import _ffi  # noqa: E402
+print(f"soak ok: {done} random cases in {budget:.0f} s on library sources {_ffi.library_sources_sha16()} ({_ffi.load().reef_version().decode()})")
