@@ -22,8 +22,10 @@
  *
  * ABI changelog (reef_abi_version()):
  *   5  round 5: device groups (reef_msm_group_*: one MSM split by window or by points, or the rows of a Hyrax commitment dealt out
- *      whole, over several GPUs of ONE process, the partial sums exchanged inside the library); reef_runtime_opts.hw_queues is
- *      the only way the library touches GPU_MAX_HW_QUEUES unless REEF_MSM_HW_QUEUES is exported (the load-time default is gone).
+ *      whole, over several GPUs of ONE process, the partial sums exchanged inside the library); reef_get_device;
+ *      reef_key_cache_timing_get; reef_runtime_opts.hw_queues is the only way the library touches GPU_MAX_HW_QUEUES unless
+ *      REEF_MSM_HW_QUEUES is exported (the load-time default of rounds 3-4 is gone); the drop-in symbols confirm a returning key's
+ *      bytes on the host whatever its size (no key upload on a hit).
  *   4  round 4: reef_runtime_init / reef_abi_version / reef_msm_ctx_attach / reef_msm_multi / reef_key_cache_info added; the drop-in symbols' key cache is one table per process
  *      (clones per calling thread) instead of one cache per thread.
  *   3  round 3: reef_msm_opts.byte_tables = 0 changed meaning from "build the byte tables in the background" to "follow the
@@ -69,10 +71,11 @@ typedef enum {
  * Montgomery form (what the Rust wrapper passes).  abort()s on error.
  * ------------------------------------------------------------------------------------------- */
 /* (A key that keeps coming back is nominated by non-cryptographic hashes of its bytes, CONFIRMED byte for byte
- * against a retained copy while the GPU already works on the nominated key, and, from its third call in the
- * process on, served from a resident pre-shifted copy; a hash collision therefore costs time, never a wrong
- * result, and nothing the caller can observe is retained.  The table of resident keys is one per process (at most 16
- * keys, REEF_MSM_KEY_CACHE_MB of device memory, default 16384): the key is built once, whichever threads call --
+ * against a retained HOST copy while the GPU already works on the nominated key (helper threads share the comparison of
+ * keys above 4 MiB), and, from its third call in the process on, served from a resident pre-shifted copy; a hash collision
+ * therefore costs time, never a wrong result, and nothing the caller can observe is retained.  The table of resident keys is
+ * one per process (at most 16 keys, REEF_MSM_KEY_CACHE_MB of device memory, default 16384, and REEF_MSM_KEY_HOST_MB of host
+ * memory, default 4096; a key stays charged while any thread's context is still attached to it): the key is built once, whichever threads call --
  * nova-snark reaches these symbols from the prover thread and from rayon workers, src/backend/framework.rs:110,
  * 668,695 -- and each calling thread serves it through its own stream and workspace on the shared tables.  On an
  * allocation failure the table is emptied and the call is served uncached.  REEF_MSM_KEY_CACHE=0 turns it off.) */
