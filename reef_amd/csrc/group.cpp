@@ -271,6 +271,9 @@ reef_status reef_msm_group_create(reef_msm_group **out, int curve, const reef_af
                         REEF_TRY(reef_msm_ctx_create(&mb.ctx, curve, bases, n, bases_loc, &o));
                     }
                     REEF_TRY(reef_msm_ctx_clone(&mb.whole, mb.ctx));
+                    // the rows context stays on ONE stream of the pool too: the first pageable copy a stream carries pays for the runtime's staging
+                    // buffers (5-20 ms, once per stream), and a member that wandered over the pool paid it again on every new stream it met
+                    if (!reef_msm_ctx_stream(mb.whole)) { set_error("reef_msm_group_create: member %zu got no stream for its rows", i); return REEF_ERR_HIP; }
                     REEF_TRY(reef_msm_ctx_set_window_split(mb.ctx, (uint32_t)i, (uint32_t)ndev));
                     mb.off = 0; mb.len = n;
                 } else {

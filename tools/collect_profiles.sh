@@ -1,7 +1,9 @@
 #!/bin/bash
 # On the MI355X box: everything profiles/ holds for a round.  usage: tools/collect_profiles.sh OUTDIR [rNN]
-out=$(realpath -m $1); R=${2:-r05}; export REEF_ROUND=$R
+#        tools/collect_profiles.sh OUTDIR rNN final   only what vouches for the FINAL build: bench line (+ rocprofv3 twin, PMC traffic), stress run, soak
+out=$(realpath -m $1); R=${2:-r05}; export REEF_ROUND=$R; MODE=${3:-all}
 mkdir -p $out; export TMPDIR=/tmp; root=$GRAFT_REPO_ROOT
+if [ "$MODE" = all ]; then
 python $root/bench.py --steps 20 --warmup 5 > $out/${R}_bench.json 2> $out/${R}_bench.err
 # per-kernel time of the same timed region: the legs that run other sizes through the same kernels after it (replay, CPU) are left out
 (cd /tmp && rm -rf /tmp/ks && rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/ks -- python $root/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-replay > $out/${R}_bench_under_rocprof.json 2>/dev/null; cp /tmp/ks/*/*kernel_stats.csv $out/${R}_kernel_stats.csv)
@@ -62,7 +64,9 @@ for m in fresh contexts-alive threads-leftover torch-first; do python $root/tool
 (cd /tmp; for L in 21 26; do rm -rf /tmp/tl$L; rocprofv3 --kernel-trace --output-format csv -d /tmp/tl$L -- python $root/tools/step_breakdown.py $L > /dev/null 2>&1; echo "## ell = $L: kernels of the last step (us)"; python $root/tools/step_timeline.py /tmp/tl$L/*/*kernel_trace.csv; done) > $out/${R}_step_timeline.txt 2>&1
 (export CHUNKS=0,5,8,10,16; python $root/tools/sweep_chunk.py 15 13; python $root/tools/sweep_chunk.py 16 15) > $out/${R}_chunk_sweep.txt 2>&1
 # round 5 additions
+fi   # MODE = all
 sha=$(cd $root && python -c "from reef_amd import _ffi; print(_ffi.library_sources_sha16())")
+if [ "$MODE" = all ]; then
 $root/reef_amd/_lib/seam_bench > $out/${R}_stateless_concurrent.txt 2>&1
 python $root/tools/time_stateless.py --threads 1,4,8 > $out/${R}_stateless_concurrent_python.txt 2>&1
 python $root/tools/time_group.py > $out/${R}_group_timing.txt 2>&1
@@ -71,6 +75,15 @@ python $root/tools/time_group.py > $out/${R}_group_timing.txt 2>&1
 $root/reef_amd/_lib/affine_probe > $out/${R}_affine_probe.txt 2>&1
 bash $root/tools/sweep_sc_mid.sh $out/${R}_sc_mid_sweep.txt
 python $root/tools/pmc_sc_step.py 26 $out/${R}_pmc_sc_step_26.json > /dev/null 2>&1; python $root/tools/pmc_sc_step.py 21 $out/${R}_pmc_sc_step_21.json > /dev/null 2>&1
+fi   # MODE = all
+if [ "$MODE" = final ]; then
+python $root/tools/pmc_traffic.py $out > $out/${R}_pmc_traffic.log 2>&1
+mkdir -p $root/profiles; cp $out/${R}_pmc_traffic.json $root/profiles/ 2>/dev/null      # bench.py reads roofline.traffic from profiles/ (refused when the kernel sources differ)
+python $root/bench.py --steps 20 --warmup 5 > $out/${R}_bench.json 2> $out/${R}_bench.err
+(cd /tmp && rm -rf /tmp/ks && rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/ks -- python $root/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-replay > $out/${R}_bench_under_rocprof.json 2>/dev/null; cp /tmp/ks/*/*kernel_stats.csv $out/${R}_kernel_stats.csv)
+(for m in 3 8; do $root/reef_amd/_lib/reef_replay cfg4 nofold devices=$m 2>/dev/null; done; $root/reef_amd/_lib/reef_replay cfg4b nofold 2>/dev/null) > $out/${R}_replay_devices.jsonl
+python $root/tools/time_group.py > $out/${R}_group_timing.txt 2>&1
+fi
 # the one-launch sum-check rounds under load, ten times the GPU suite's count, all three orderings of the hand-over (sumcheck_kernels.inc: SC_ORDER_*)
 (echo "# reef_amd/_lib/sc_stress <ell> <steps> load: one folding step repeated under k_accum0 + streaming load, every coefficient triple against the two-launch form; library sources $sha"
  run() { env REEF_SC_FENCE=$1 $3 $root/reef_amd/_lib/sc_stress $2 $4 load; }
