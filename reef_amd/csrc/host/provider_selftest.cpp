@@ -54,6 +54,20 @@ int main() {
         out += "], \"hyrax_symbols\": [";
         for (size_t i = 0; i < rows; ++i) out += std::string(i ? ", " : "") + "\"" + chex<REEF_PALLAS>(c2[i]) + "\"";
         out += "], ";
+        // ---- the same commitments with the keys on three members of a device group (one process; the ordinals repeat device 0)
+        {
+            CommitmentGensOnDevices<REEF_PALLAS> ckd(gens.data(), n, {0, 0, 0}, &h);
+            out += "\"group_commit_blind\": \"" + chex<REEF_PALLAS>(ckd.commit(v.data(), n, blind.data())) + "\", ";
+            out += "\"group_commit\": \"" + chex<REEF_PALLAS>(ckd.commit(v.data(), n)) + "\", ";
+            CommitmentGensOnDevices<REEF_PALLAS> gvd(rg.data(), cols, {0, 0, 0}, &h);
+            const auto d1 = gvd.commit_rows(z.data(), rows, cols, bl.data());
+            const auto d2 = gvd.commit_symbols(sym.data(), rows, cols, 8, bl.data());
+            out += "\"group_hyrax\": [";
+            for (size_t i = 0; i < rows; ++i) out += std::string(i ? ", " : "") + "\"" + chex<REEF_PALLAS>(d1[i]) + "\"";
+            out += "], \"group_hyrax_symbols\": [";
+            for (size_t i = 0; i < rows; ++i) out += std::string(i ? ", " : "") + "\"" + chex<REEF_PALLAS>(d2[i]) + "\"";
+            out += "], ";
+        }
         // ---- row binding of prove_eval at a fixed point (canonical integers)
         std::vector<reef_fe> point(vars);
         for (size_t j = 0; j < vars; ++j) point[j] = reef_fe{{0x1f83d9abfb41bd6bULL + j, 0x5be0cd19137e2179ULL, 0x3c6ef372fe94f82bULL, 0x0a54ff53a5f1d36fULL}};

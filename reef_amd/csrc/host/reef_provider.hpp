@@ -8,6 +8,8 @@
 //   CommitmentGens<CURVE>::commit_folded(..)      any commitment over folded generators (a slice of them), folds recorded not performed
 //   HyraxPC<CURVE>::commit / commit_symbols       HyraxPC::commit(&poly)                 src/backend/commitment.rs:187
 //   HyraxPC<CURVE>::bind_rows                     first step of HyraxPC::prove_eval      src/backend/commitment.rs:371-391 (and :357)
+//   CommitmentGensOnDevices<CURVE>                the same key on several GPUs of this process (device groups, reef_msm.h section 5):
+//       ::commit / ::commit_rows / ::commit_symbols   CE::commit split by Pippenger window over the devices, HyraxPC::commit rows dealt out whole
 //   SumCheck                                      gen_eq_table / linear_mle_product      src/backend/r1cs_helper.rs:441-544, driven as in r1cs.rs:2318-2385
 //   compress()                                    Commitment::compress                   src/backend/commitment.rs:195,351,365
 //
@@ -100,6 +102,55 @@ template <int CURVE> class CommitmentGens {
 
   private:
     reef_msm_ctx *ctx_ = nullptr;
+    size_t n_;
+    reef_affine h_ = {};
+    bool has_h_;
+};
+
+// The same commitment key kept on several GPUs of ONE process -- Reef's prover is one process (src/backend/main.rs:82) -- through the
+// library's device groups: CE::commit is split by Pippenger window over the devices (the 96-byte partial sums are exchanged and added
+// inside the library), the rows of HyraxPC::commit are dealt out whole.  `devices` may repeat an ordinal.
+template <int CURVE> class CommitmentGensOnDevices {
+  public:
+    CommitmentGensOnDevices(const reef_affine *gens, size_t n, const std::vector<int> &devices, const reef_affine *h = nullptr, uint32_t split = REEF_SPLIT_WINDOWS)
+        : n_(n), has_h_(h != nullptr) {
+        reef_msm_opts o = {};
+        o.bucket_groups = 1;
+        reef_msm_group_opts g = {};
+        g.split = split;
+        check(reef_msm_group_create(&grp_, CURVE, gens, n, REEF_HOST, &o, devices.data(), devices.size(), &g), "reef_msm_group_create");
+        if (h) h_ = *h;
+    }
+    ~CommitmentGensOnDevices() { reef_msm_group_destroy(grp_); }
+    CommitmentGensOnDevices(const CommitmentGensOnDevices &) = delete;
+    CommitmentGensOnDevices &operator=(const CommitmentGensOnDevices &) = delete;
+    size_t len() const { return n_; }
+
+    reef_jacobian commit(const reef_fe *v, size_t n, const reef_fe *blind = nullptr) const {
+        reef_jacobian out;
+        if (blind) {
+            if (!has_h_) throw std::logic_error("commit with a blind needs the blinding generator");
+            check(reef_msm_group_rows(grp_, v, 1, n, REEF_HOST, true, 0, blind, &h_, &out), "reef_msm_group_rows");
+        } else {
+            check(reef_msm_group_msm(grp_, v, n, REEF_HOST, true, &out), "reef_msm_group_msm");
+        }
+        return out;
+    }
+    // HyraxPC::commit(&poly) over the devices: rows x row_len field elements / one-byte symbols, one commitment per row
+    std::vector<reef_jacobian> commit_rows(const reef_fe *poly, size_t rows, size_t row_len, const reef_fe *blinds, uint32_t max_scalar_bits = 0) const {
+        std::vector<reef_jacobian> out(rows);
+        check(reef_msm_group_rows(grp_, poly, rows, row_len, REEF_HOST, true, max_scalar_bits, blinds, blinds ? &h_ : nullptr, out.data()), "reef_msm_group_rows");
+        return out;
+    }
+    std::vector<reef_jacobian> commit_symbols(const uint8_t *symbols, size_t rows, size_t row_len, uint32_t symbol_bits, const reef_fe *blinds) const {
+        std::vector<reef_jacobian> out(rows);
+        check(reef_msm_group_rows_symbols(grp_, symbols, rows, row_len, REEF_HOST, symbol_bits, blinds, blinds ? &h_ : nullptr, true, out.data()),
+              "reef_msm_group_rows_symbols");
+        return out;
+    }
+
+  private:
+    reef_msm_group *grp_ = nullptr;
     size_t n_;
     reef_affine h_ = {};
     bool has_h_;

@@ -17,6 +17,7 @@ reference's call sites and so that a maintainer can see what each Rust method ma
         (ipa_pc inside CompressedSNARK::prove, framework.rs:695)      CommitmentGens.fold_lazy -> FoldedGens (fold recorded, never performed)
     HyraxPC::commit(&poly)                             [R]    HyraxPC.commit(poly)
         (commitment.rs:187)
+    the same on the GPUs of a node, from one process          CommitmentGens(..., devices=[0, 1, ..]): device groups
     Commitment::compress()                             [R]    Commitment.compress()
         (commitment.rs:195,351,365,425,427,431)
 
@@ -83,8 +84,13 @@ class CommitmentGens:
     resident on the GPU."""
 
     def __init__(self, curve, bases: np.ndarray, h: Optional[np.ndarray] = None, *, precompute: bool = True,
-                 window_bits: int = 0):
+                 window_bits: int = 0, devices: Optional[Sequence[int]] = None, split: int = msm.SPLIT_WINDOWS):
+        """devices: keep the key on several GPUs of this process (reef_msm_group_*, include/reef_msm.h section 5): commitments are split by
+        Pippenger window (or by points) over them and Hyrax rows dealt out whole -- same points, whatever the devices."""
         self.curve = msm.curve_id(curve)
+        self._devices = None if devices is None else [int(d) for d in devices]
+        self._split = split
+        self._group: Optional[msm.MsmGroup] = None
         self.bases = np.ascontiguousarray(bases, dtype=np.uint64).reshape(-1, 8)
         self.h = None if h is None else np.ascontiguousarray(h, dtype=np.uint64).reshape(8)
         self._precompute = precompute
@@ -100,21 +106,37 @@ class CommitmentGens:
                                        bucket_groups=1 if self._precompute else 0)
         return self._ctx
 
+    def _on_devices(self) -> Optional[msm.MsmGroup]:
+        if self._devices is None:
+            return None
+        if self._group is None:
+            self._group = msm.MsmGroup(self.curve, self.bases, self._devices, split=self._split, window_bits=self._window_bits,
+                                       bucket_groups=1 if self._precompute else 0)
+        return self._group
+
     def close(self) -> None:
         if self._ctx is not None:
             self._ctx.close()
             self._ctx = None
+        if self._group is not None:
+            self._group.close()
+            self._group = None
 
     # CE::commit(&gens, &v, &blind)
     def commit(self, v: np.ndarray, blind: Optional[np.ndarray] = None, *, is_mont: bool = True) -> Commitment:
         v = np.ascontiguousarray(v, dtype=np.uint64).reshape(-1, 4)
         if v.shape[0] > len(self):
             raise ValueError(f"vector of {v.shape[0]} scalars exceeds {len(self)} generators")
+        grp = self._on_devices()
         if blind is None:
-            return Commitment(self.curve, self._context().msm(v, is_mont=is_mont))
+            return Commitment(self.curve, grp.msm(v, is_mont=is_mont) if grp is not None else self._context().msm(v, is_mont=is_mont))
         if self.h is None:
             raise ValueError("these generators have no blinding generator")
         b = np.ascontiguousarray(blind, dtype=np.uint64).reshape(1, 4)
+        if grp is not None:
+            if self._split != msm.SPLIT_WINDOWS:
+                raise ValueError("a commitment with a blind needs the whole key on every device (split = windows)")
+            return Commitment(self.curve, grp.msm_rows(v, 1, v.shape[0], is_mont=is_mont, blinds=b, h=self.h)[0])
         out = self._context().msm_rows(v, 1, v.shape[0], is_mont=is_mont, blinds=b, h=self.h)
         return Commitment(self.curve, out[0])
 
@@ -216,8 +238,8 @@ class HyraxPC:
         if row_len > len(self.gens_v):
             raise ValueError("not enough row generators")
         blinds = np.ascontiguousarray(blinds, dtype=np.uint64).reshape(rows, 4)
-        out = self.gens_v._context().msm_rows(poly, rows, row_len, is_mont=is_mont, max_scalar_bits=max_scalar_bits,
-                                              blinds=blinds, h=self.gens_v.h)
+        target = self.gens_v._on_devices() or self.gens_v._context()        # rows dealt out whole over the devices, or one context
+        out = target.msm_rows(poly, rows, row_len, is_mont=is_mont, max_scalar_bits=max_scalar_bits, blinds=blinds, h=self.gens_v.h)
         comp = msm.normalize(self.gens_v.curve, out, affine=False, compressed=True)[1]
         return out, comp
 
@@ -233,8 +255,8 @@ class HyraxPC:
         if row_len > len(self.gens_v):
             raise ValueError("not enough row generators")
         blinds = np.ascontiguousarray(blinds, dtype=np.uint64).reshape(rows, 4)
-        out = self.gens_v._context().msm_rows_symbols(symbols, rows, row_len, symbol_bits, blinds=blinds, h=self.gens_v.h,
-                                                      blinds_are_mont=blinds_are_mont)
+        target = self.gens_v._on_devices() or self.gens_v._context()
+        out = target.msm_rows_symbols(symbols, rows, row_len, symbol_bits, blinds=blinds, h=self.gens_v.h, blinds_are_mont=blinds_are_mont)
         comp = msm.normalize(self.gens_v.curve, out, affine=False, compressed=True)[1]
         return out, comp
 

@@ -219,6 +219,9 @@ def test_cpp_provider_mirror_matches_oracle(gpu_lib, cref):
     want = cref.compress(0, cref.row_msm(0, rg, z, rows, cols, h=h, blinds=bl))
     want_rows = [want[32 * i:32 * i + 32].hex() for i in range(rows)]
     assert got["hyrax"] == want_rows and got["hyrax_symbols"] == want_rows
+    # the same through CommitmentGensOnDevices (device groups: three members on device 0)
+    assert got["group_commit"] == got["commit"] and got["group_commit_blind"] == got["commit_blind"]
+    assert got["group_hyrax"] == want_rows and got["group_hyrax_symbols"] == want_rows
     # prove_eval row binding
     zc = [int(x) for x in cref.gen_scalars(0, 11, rows * cols, kind=2, small_bound=131, mont=False)[:, 0]]
     point = [(0x1f83d9abfb41bd6b + j) | 0x5be0cd19137e2179 << 64 | 0x3c6ef372fe94f82b << 128 | 0x0a54ff53a5f1d36f << 192 for j in range(9)]
@@ -320,3 +323,42 @@ def test_ipa_cross_terms_on_byte_tables(gpu_lib, cref):
             gens = cref.fold(cid, np.ascontiguousarray(gens[:n_k]), w1, w2)
             w1s.append(w1)
             w2s.append(w2)
+
+
+@pytest.mark.parametrize("devices", [[0, 0], [0, 0, 0, 0, 0]])
+def test_commitment_gens_on_several_devices_give_the_same_points(devices, gpu_lib, cref):
+    """CommitmentGens(..., devices=[..]): the provider mirror over the library's device groups (include/reef_msm.h section 5; the ordinals
+    repeat device 0 on a one-GPU box) -- CE::commit with and without a blind (commitment.rs:350,361; framework.rs:668) and HyraxPC::commit from
+    field elements and from document symbols (commitment.rs:187) return the points the one-device mirror and the oracle give."""
+    from reef_amd import msm, provider as P
+    cid, name = 0, "pallas"
+    n = 3001
+    bases = cref.gen_bases_ap(cid, 77, 5, n)
+    H = cref.gen_bases_ap(cid, 0xB11D, 1, 1)[0]
+    v = cref.gen_scalars(cid, 3, n, kind=1)
+    b = cref.gen_scalars(cid, 4, 1)
+    one = P.CommitmentGens(name, bases, H)
+    for split in (msm.SPLIT_WINDOWS, msm.SPLIT_POINTS):
+        many = P.CommitmentGens(name, bases, H, devices=devices, split=split)
+        assert many.commit(v) == one.commit(v)
+        assert many.commit(v).compress() == cref.compress(cid, cref.msm_pippenger(cid, bases, v, threads=4))
+        if split == msm.SPLIT_WINDOWS:
+            assert many.commit(v, b[0]) == one.commit(v, b[0])
+            assert many.commit(v, b[0]).compress() == cref.compress(cid, cref.row_msm(cid, bases, v, 1, n, h=H, blinds=b, threads=4))
+        else:
+            with pytest.raises(ValueError):
+                many.commit(v, b[0])
+        many.close()
+    num_vars = 13
+    left, right = P.HyraxPC.compute_factored_lens(num_vars)
+    rows, row_len = 1 << left, 1 << right
+    gens_v = P.CommitmentGens(name, bases[:row_len].copy(), H, devices=devices)
+    poly = cref.gen_scalars(cid, 7, rows * row_len, kind=2, small_bound=7)
+    canon = cref.gen_scalars(cid, 7, rows * row_len, kind=2, small_bound=7, mont=False)
+    blinds = cref.gen_scalars(cid, 8, rows)
+    exp = cref.compress(cid, cref.row_msm(cid, gens_v.bases, poly, rows, row_len, h=H, blinds=blinds, threads=4))
+    pc = P.HyraxPC(gens_v)
+    assert pc.commit(poly, blinds)[1].tobytes() == exp
+    assert pc.commit_symbols(canon[:, 0].astype(np.uint8), blinds, 3)[1].tobytes() == exp
+    gens_v.close()
+    one.close()
