@@ -162,3 +162,25 @@ def test_groups_from_several_threads_and_bad_arguments(gpu_lib, cref, key):
     devs = (ctypes.c_int * 2)(0, lib.reef_device_count())                          # the second ordinal does not exist
     assert lib.reef_msm_group_create(ctypes.byref(h), 0, bases.ctypes.data, n, 0, None, devs, 2, None) == 1
     assert b"visible" in lib.reef_last_error()
+
+
+def test_group_rows_at_the_baseline_document_shape_dlog_property(gpu_lib):
+    """BASELINE configs[3]: the Hyrax commitment of a 16 MiB DNA document (4096 rows of 8192 three-bit symbols, commitment.rs:173-187) with the
+    rows dealt out over 8 / 3 members, from host bytes: rows of every member against the discrete-log closed form (generators in arithmetic
+    progression), and the whole result against one context."""
+    from oracle.pasta_oracle import CURVES
+    from reef_amd import msm
+    C = CURVES["pallas"]
+    rows, row_len, bits, k0, d = 4096, 8192, 3, 0xFEED, 3
+    doc = np.random.default_rng(0xD0C).integers(0, 7, size=(rows, row_len), dtype=np.uint8)
+    flat = np.ascontiguousarray(doc.reshape(-1))
+    gens = msm.gen_bases("pallas", k0, d, row_len, device=True)
+    with msm.MsmContext("pallas", gens, row_len) as one:
+        ref = msm.compress("pallas", one.msm_rows_symbols(flat, rows, row_len, bits))
+    for members in (8, 3):
+        with msm.MsmGroup("pallas", gens, [0] * members, row_len, split=msm.SPLIT_WINDOWS) as g:
+            got = g.msm_rows_symbols(flat, rows, row_len, bits)
+        assert msm.compress("pallas", got) == ref, members
+        for r in (0, rows // members - 1, rows // members, rows // 2 + 1, rows - 1):         # the edges of the members' blocks
+            dl = sum(int(v) * (k0 + j * d) for j, v in enumerate(doc[r].tolist())) % C.order
+            assert msm.compress("pallas", got[r].copy()) == C.compress(C.mul(dl, C.gen)), (members, r)
