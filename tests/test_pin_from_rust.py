@@ -42,6 +42,31 @@ def _inputs(case):
 
 
 # ------------------------------------------------------------------------------------------------ CPU: the oracle ----
+def test_reefs_own_frontend_and_cost_model_against_the_restatements():
+    """`reef_frontend` (cargo run --features reef-frontend): the automaton SAFA::new builds and costs.rs on it, from Reef's own code, against
+    oracle/safa_shape.py and oracle/costs_oracle.py."""
+    from oracle import costs_oracle as K, safa_shape as S
+    cases = section("reef_frontend")
+    if not cases:
+        pytest.skip("rust_pin was built without --features reef-frontend")
+    from oracle.gen_replay_shapes import BRCA1_A, BRCA1_B, brca
+    regexes = {".*b": ".*b", ".*password.*": ".*password.*", "^baa$": "^baa$", "baa": "baa"}
+    for c in cases:
+        rx = regexes.get(c["regex"])
+        if rx is None:                                   # the BRCA regexes are printed shortened: rebuild them from their length
+            for cand in (brca(c["doc_bytes"], 8129, [BRCA1_A]), brca(c["doc_bytes"], 5784, BRCA1_B)):
+                if len(cand) == c["regex_len"]:
+                    rx = cand
+        assert rx is not None, c["regex"]
+        sh = S.shape(rx, c["alphabet_size"])
+        assert (sh.num_states, sh.num_edges, sh.max_skip_offset) == (c["num_states"], c["num_edges"], c["max_skip_offset"]), c["regex"]
+        udoc_len = K.next_power_of_two(c["doc_bytes"] + 2)
+        hybrid_len = 2 * max(udoc_len, K.next_power_of_two(sh.num_edges)) if c["hybrid"] else None
+        safa = K.SafaShape(num_states=sh.num_states, num_edges=sh.num_edges, max_offset=sh.max_offsets, max_branches=1, max_stack=1)
+        assert K.full_round_cost_model(safa, c["batch"], udoc_len, c["hybrid"], hybrid_len, False) == c["full_round_cost_model"], c["regex"]
+
+
+
 def test_layout_is_montgomery_limbs_and_zero_identities():
     """reef_fe = 4 x u64 LE Montgomery limbs (R = 2^256); reef_affine identity = (0, 0); reef_jacobian identity has z = 0."""
     for lay in section("layout"):

@@ -276,6 +276,48 @@ fn main() {
                "first_squeeze": fq_hex(&claim_r), "tag": tag_hex, "rounds": rounds, "t_final": fq_hex(&t[0]), "eq_final": fq_hex(&e[0])})
     };
 
+    // ---- Reef's own frontend and cost model (feature reef-frontend): the automaton SAFA::new builds for the regexes oracle/gen_replay_shapes.py
+    //      takes from the reference's scripts, and costs.rs evaluated on it -- what oracle/safa_shape.py and oracle/costs_oracle.py restate
+    #[cfg(feature = "reef-frontend")]
+    let reef_frontend: Value = {
+        use reef::backend::costs::{full_round_cost_model, opt_cost_model_select};
+        use reef::frontend::regex::re;
+        use reef::frontend::safa::SAFA;
+        let ascii: String = (0u32..128).filter_map(std::char::from_u32).collect();   // src/config.rs:229-233
+        let brca1_a = "ATGGGCTACAGAAACCGTGCCAAAAGACTTCTACAGAGTGAACCCGAAAATCCTTCCTTG";   // tests/scripts/dna.sh:6
+        let brca1_b = ["ATGCTGAAACTTCTCAACCAGAAGAAAGGGCCTTCACAGTGTCCTTTATGTAAGAATGATATAACCAAAAG",
+                       "AGCCTACAAGAAAGTACGAGATTTAGTCAACTTGTTGAAGAGCTATTGAAAATCATTTGTGCTTTTCAGCTTGACACAGGTTTGGAGT",
+                       "ATGCAAACAGCTATAATTTTGCAAAAAAGGAAAATAACTCTCCTGAACATCTAAAAGATGAAGTTTCTATCATCCAAAGTATGGGCTACAGAAACCGTGCCAAAAGACTTCTACAGAGTGAACCCGAAAATCCTTCCTTG"];   // dna.sh:7
+        let doc16: usize = 1 << 24;
+        let cases: Vec<(String, String, usize, bool, usize)> = vec![      // (regex, alphabet, document bytes, hybrid, batch; 0 = chosen by the model)
+            (".*b".into(), ascii.clone(), 9, false, 0),
+            (".*password.*".into(), ascii.clone(), 1 << 20, false, 0),
+            (format!("^.{{{}}}{}", doc16 - 10000 + 8129, brca1_a), "ACGT".into(), doc16, true, 32),
+            (format!("^.{{{}}}{}", doc16 - 10000 + 5784, brca1_b.join(".*")), "ACGT".into(), doc16, true, 32),
+            ("^baa$".into(), "ab".into(), 3, false, 2),          // the automata of safa.rs's own tests (safa.rs:574-610)
+            ("baa".into(), "ab".into(), 8, false, 2),
+        ];
+        let mut out = vec![];
+        for (rx, ab, doc_bytes, hybrid, batch) in cases {
+            let r = re::simpl(re::new(&rx));
+            let safa = SAFA::new(&ab, &r);
+            let udoc_len = (doc_bytes + 2).next_power_of_two();          // framework.rs:997-1008
+            let max_offsets = safa.max_skip_offset().max(1) + 2;          // r1cs.rs:108-110
+            let hybrid_len = if hybrid { Some(2 * udoc_len.max(safa.num_edges().next_power_of_two())) } else { None };   // r1cs.rs:481-487 (the table is far smaller than the document here)
+            // the solution lengths NFA::new would hand the model are not reachable without building the whole converter; the cost at a FIXED batch is
+            let b = if batch == 0 { 2 } else { batch };
+            let cost = full_round_cost_model(&safa, b, udoc_len, hybrid, hybrid_len, false, max_offsets, 1, 1);
+            out.push(json!({"regex": if rx.len() > 120 { format!("{}...{}", &rx[..60], &rx[rx.len() - 40..]) } else { rx.clone() }, "regex_len": rx.len(),
+                            "alphabet_size": ab.chars().count(), "doc_bytes": doc_bytes, "hybrid": hybrid, "batch": b,
+                            "num_states": safa.num_states(), "num_edges": safa.num_edges(), "max_skip_offset": safa.max_skip_offset(),
+                            "full_round_cost_model": cost}));
+        }
+        let _ = opt_cost_model_select;   // (its inputs need NFA::new's path lengths; see tests/test_safa_shape.py for how the oracle derives them)
+        json!(out)
+    };
+    #[cfg(not(feature = "reef-frontend"))]
+    let reef_frontend: Value = Value::Null;
+
     let doc = json!({
         "generated_by": "tools/rust_pin (cargo run --release); see tools/rust_pin/README.md",
         "crates": {"fil_pasta_curves": "0.5.2 (repr-c)", "pasta-msm": env!("CARGO_PKG_VERSION"), "neptune": "8.1.0", "nova-snark": "git sga001/Nova (state the rev)"},
@@ -285,6 +327,7 @@ fn main() {
         "commitment_gens": commitment_gens,
         "poseidon": poseidon,
         "linear_mle": linear_mle,
+        "reef_frontend": reef_frontend,
     });
     println!("{}", serde_json::to_string_pretty(&doc).unwrap());
 }
