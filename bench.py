@@ -68,6 +68,9 @@ def parse():
     p.add_argument("--single-process", action="store_true",
                    help="with --gpus N and NO torchrun: ONE process drives N members through the library's device groups (reef_msm_group_*, "
                         "include/reef_msm.h section 5) -- what a Rust prover can call; members beyond the visible devices repeat ordinals (labelled)")
+    p.add_argument("--group-exchange", default="peer", choices=["peer", "host", "rccl"],
+                   help="--single-process: how the members' 96-byte partial sums reach devices[0] (include/reef_msm.h section 5: hipMemcpyPeerAsync, host-mapped slots, or "
+                        "ncclSend/ncclRecv on a single-process RCCL communicator)")
     p.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                    help="nccl = RCCL over xGMI (default); gloo = host-staged gather (debug / boxes without RCCL), labelled as such")
     return p.parse_args()
@@ -404,6 +407,7 @@ def single_process_main(a):
     T = max(1, a.streams)
     MPS = max(1, a.msms_per_step)
     msm.set_device(devices[0])
+    EX = {"peer": msm.EXCHANGE_PEER, "host": msm.EXCHANGE_HOST, "rccl": msm.EXCHANGE_RCCL}[a.group_exchange]
 
     def in_flight(calls, fns):
         """`calls` calls dealt round-robin to len(fns) caller threads; -> seconds"""
@@ -428,7 +432,7 @@ def single_process_main(a):
     # ---- the timed region: weak scaling by points
     bases_all = msm.gen_bases(a.curve, k0, d, N * n, device=True)
     sc_all = msm.gen_scalars(a.curve, 0x5EEF, N * n, kind=kind, mont=True, device=True)
-    wg = [msm.MsmGroup(a.curve, bases_all, devices, N * n, split=msm.SPLIT_POINTS, window_bits=a.window_bits, bucket_groups=groups_opt, chunk=a.chunk)
+    wg = [msm.MsmGroup(a.curve, bases_all, devices, N * n, split=msm.SPLIT_POINTS, exchange=EX, window_bits=a.window_bits, bucket_groups=groups_opt, chunk=a.chunk)
           for _ in range(T)]
     info = wg[0].info()
     last = [None] * T
@@ -483,7 +487,7 @@ def single_process_main(a):
     # ---- strong scaling: ONE 2^logn-point MSM over the members, by window and by points; latency (one call in flight) and T in flight
     strong = {"one_msm_points": n, "in_flight": T, "one_gpu_ms_per_msm": one_gpu_ms}
     for name, sp in (("windows", msm.SPLIT_WINDOWS), ("points", msm.SPLIT_POINTS)):
-        gs = [msm.MsmGroup(a.curve, bases1, devices, n, split=sp, window_bits=a.window_bits, bucket_groups=groups_opt, chunk=a.chunk) for _ in range(T)]
+        gs = [msm.MsmGroup(a.curve, bases1, devices, n, split=sp, exchange=EX, window_bits=a.window_bits, bucket_groups=groups_opt, chunk=a.chunk) for _ in range(T)]
         res = [None] * T
         gf = [(lambda j: (lambda: res.__setitem__(j, gs[j].msm(sc1, n))))(j) for j in range(T)]
         in_flight(T, gf)
@@ -531,7 +535,9 @@ def single_process_main(a):
                       "devices": devices, "distinct_devices": info["distinct_devices"], "visible_devices": visible,
                       "devices_note": None if info["distinct_devices"] == N else f"{N} members on {info['distinct_devices']} device(s): ordinals repeat, NOT a scaling measurement",
                       "exchange": info["exchange"] + (" (hipMemcpyPeerAsync of the 96-byte partial sums to devices[0], sum kernel there; in place where members share a device)"
-                                                     if info["exchange"] == "peer" else ""),
+                                                     if info["exchange"] == "peer" else
+                                                     " (ncclSend/ncclRecv pairs in one ncclGroup on a single-process communicator, RCCL opened at run time; sum kernel on devices[0])"
+                                                     if info["exchange"] == "rccl" else ""),
                       "peer_members": info["peer_members"], "key_points_per_member": info["key_points"],
                       "scalars": "device-resident on devices[0]; members on other devices fetch their slice with a peer copy INSIDE the timed call",
                       "ms_per_msm": weak_ms, "host_scalars_ms_per_msm": host_ms,
@@ -833,19 +839,24 @@ def main():
                     import subprocess
                     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "GROUP_RANK", "ROLE_RANK",
                                                                           "LOCAL_WORLD_SIZE", "ROLE_WORLD_SIZE", "TORCHELASTIC_RUN_ID") and not k.startswith("TORCHELASTIC")}
-                    child = subprocess.run([sys.executable, os.path.abspath(__file__), "--gpus", str(a.gpus), "--single-process", "--logn", str(a.logn), "--steps", "2", "--warmup", "1",
-                                            "--msms-per-step", "12", "--curve", a.curve], capture_output=True, text=True, timeout=240, env=env)
-                    lines = [ln for ln in child.stdout.splitlines() if ln.startswith("{")]
-                    if child.returncode == 0 and lines:
-                        cl = json.loads(lines[-1])
-                        cc = cl["config"]
-                        strong["single_process"] = {"value": cl["value"], "ms_per_msm": cc["ms_per_msm"], "host_scalars_ms_per_msm": cc["host_scalars_ms_per_msm"],
-                                                    "devices": cc["devices"], "distinct_devices": cc["distinct_devices"], "exchange": cc["exchange"], "peer_members": cc["peer_members"],
-                                                    "check": cc["check"], "strong_scaling": cc["strong_scaling"], "devices_note": cc["devices_note"],
-                                                    "note": "`bench.py --gpus N --single-process` run by rank 0 as a child while the other ranks wait: one process, N members, "
-                                                            "the library's own exchange (no torch.distributed); value = pairs/s of one N x 2^logn-point MSM per call, weak scaling by points"}
-                    else:
-                        strong["single_process"] = {"error": f"child exited with {child.returncode}: {child.stderr[-400:]}"}
+                    for field, ex in (("single_process", "peer"), ("single_process_rccl", "rccl")):
+                        child = subprocess.run([sys.executable, os.path.abspath(__file__), "--gpus", str(a.gpus), "--single-process", "--group-exchange", ex, "--logn", str(a.logn),
+                                                "--steps", "2", "--warmup", "1", "--msms-per-step", "12", "--curve", a.curve], capture_output=True, text=True, timeout=240, env=env)
+                        lines = [ln for ln in child.stdout.splitlines() if ln.startswith("{")]
+                        if child.returncode == 0 and lines:
+                            cl = json.loads(lines[-1])
+                            cc = cl["config"]
+                            strong[field] = {"value": cl["value"], "ms_per_msm": cc["ms_per_msm"], "host_scalars_ms_per_msm": cc["host_scalars_ms_per_msm"],
+                                             "devices": cc["devices"], "distinct_devices": cc["distinct_devices"], "exchange": cc["exchange"], "peer_members": cc["peer_members"],
+                                             "check": cc["check"], "strong_scaling": cc["strong_scaling"], "devices_note": cc["devices_note"],
+                                             "note": "`bench.py --gpus N --single-process` run by rank 0 as a child while the other ranks wait: one process, N members, "
+                                                     "the library's own exchange (no torch.distributed); value = pairs/s of one N x 2^logn-point MSM per call, weak scaling by points"}
+                            if ex == "rccl":                      # the same protocol, the 96-byte partial sums as ncclSend/ncclRecv on a single-process communicator
+                                strong[field].pop("note")
+                                strong[field].pop("devices")
+                        else:
+                            strong[field] = {"error": f"child exited with {child.returncode}: {child.stderr[-400:]}"}
+                            break
                 except Exception as e:
                     strong["single_process"] = {"error": str(e)}
             dist.barrier()

@@ -22,7 +22,8 @@
  *
  * ABI changelog (reef_abi_version()):
  *   5  round 5: device groups (reef_msm_group_*: one MSM split by window or by points, or the rows of a Hyrax commitment dealt out
- *      whole, over several GPUs of ONE process, the partial sums exchanged inside the library); reef_get_device;
+ *      whole, over several GPUs of ONE process, the partial sums exchanged inside the library: peer copies, host slots, or a
+ *      single-process RCCL communicator loaded at run time); reef_get_device;
  *      reef_key_cache_timing_get; reef_runtime_opts.hw_queues is the only way the library touches GPU_MAX_HW_QUEUES unless
  *      REEF_MSM_HW_QUEUES is exported (the load-time default of rounds 3-4 is gone); the drop-in symbols confirm a returning key's
  *      bytes on the host whatever its size (no key upload on a hit).
@@ -464,6 +465,14 @@ reef_status reef_bench_fmul(int field, uint32_t iters, double *products_per_s);
  * kernel (RCCL has no elliptic-curve reduction and the payload is 96 bytes per member: latency, not bandwidth).
  * REEF_EXCHANGE_HOST -- the labelled fallback: every member's last kernel stores into its slot of host-mapped pinned memory,
  * the host waits for all members and the slots are summed on member 0's device.  gopts->exchange = 0 takes PEER.
+ * REEF_EXCHANGE_RCCL -- the exchange north_star words ("an RCCL reduce of the partial sums over xGMI"), from one process: a
+ * single-process communicator over the group's DISTINCT devices (ncclCommInitAll at reef_msm_group_create; RCCL is loaded at
+ * run time -- librccl.so.1, or the file REEF_RCCL_LIB names -- so the library carries no link-time dependency on it, and the
+ * creation FAILS, with the loader's message, where it cannot be loaded: no silent fallback).  Per call: one ncclGroup of
+ * ncclSend (member i's 96 bytes, on its device's stream) / ncclRecv (member 0's device, into slot i) pairs, then the same sum
+ * kernel.  RCCL offers no reduction over curve points, so the "reduce" is a gather plus k_sum_points whichever exchange is
+ * chosen.  Every member but member 0 goes through a send/receive pair, also a member that shares member 0's device (a rank
+ * sending to itself): a one-GPU box runs the calls an eight-GPU node runs, with other peers.
  *
  * devices[] may REPEAT an ordinal: a group of 2 / 3 / 8 members on device 0 runs every code path on a one-GPU box (that is how
  * tests/test_gpu_group.py covers it); members that share a device share the resident key (clones).  Results are identical to
@@ -473,7 +482,7 @@ reef_status reef_bench_fmul(int field, uint32_t iters, double *products_per_s);
  * ------------------------------------------------------------------------------------------- */
 typedef struct reef_msm_group reef_msm_group;
 enum { REEF_SPLIT_WINDOWS = 0, REEF_SPLIT_POINTS = 1 };
-enum { REEF_EXCHANGE_DEFAULT = 0, REEF_EXCHANGE_PEER = 1, REEF_EXCHANGE_HOST = 2 };
+enum { REEF_EXCHANGE_DEFAULT = 0, REEF_EXCHANGE_PEER = 1, REEF_EXCHANGE_HOST = 2, REEF_EXCHANGE_RCCL = 3 };
 typedef struct {
     uint32_t split;        /* REEF_SPLIT_* */
     uint32_t exchange;     /* REEF_EXCHANGE_* */

@@ -6,8 +6,12 @@
 // Why one process: Reef's prover is a single Rust process (src/backend/main.rs:82, src/backend/framework.rs:81-166) and the only
 // way it can reach eight GPUs is through calls it makes itself; reef_amd/distributed.py (one process per GPU over
 // torch.distributed) stays the harness the driver's torchrun launches, this is what a Rust binding calls.
+#include <dlfcn.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
+
+#include <rccl/rccl.h>   // declarations only: the library is opened at run time (Rccl below), nothing links against it
 
 #include <atomic>
 #include <condition_variable>
@@ -32,6 +36,57 @@ struct DevGuard {
         if (switched) (void)hipSetDevice(prev);
     }
 };
+
+// REEF_EXCHANGE_RCCL: librccl opened at run time.  One table per process; a failed load is remembered with its message.
+struct Rccl {
+    void *handle = nullptr;
+    char why[384] = "";
+    decltype(&ncclCommInitAll) CommInitAll = nullptr;
+    decltype(&ncclCommDestroy) CommDestroy = nullptr;
+    decltype(&ncclGroupStart) GroupStart = nullptr;
+    decltype(&ncclGroupEnd) GroupEnd = nullptr;
+    decltype(&ncclSend) Send = nullptr;
+    decltype(&ncclRecv) Recv = nullptr;
+    decltype(&ncclGetErrorString) GetErrorString = nullptr;
+    decltype(&ncclGetVersion) GetVersion = nullptr;
+    bool ok() const { return handle != nullptr; }
+};
+static Rccl &rccl() {
+    static Rccl r;
+    static std::once_flag once;
+    std::call_once(once, [] {
+        const char *name = getenv("REEF_RCCL_LIB");
+        if (!name || !*name) name = "librccl.so.1";
+        void *h = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+        if (!h) {
+            const char *e = dlerror();
+            snprintf(r.why, sizeof r.why, "dlopen(%s): %s", name, e ? e : "failed");
+            return;
+        }
+        bool all = true;
+        auto sym = [&](const char *s) -> void * {
+            void *p = dlsym(h, s);
+            if (!p && all) { snprintf(r.why, sizeof r.why, "%s has no symbol %s", name, s); all = false; }
+            return p;
+        };
+        r.CommInitAll = (decltype(r.CommInitAll))sym("ncclCommInitAll");
+        r.CommDestroy = (decltype(r.CommDestroy))sym("ncclCommDestroy");
+        r.GroupStart = (decltype(r.GroupStart))sym("ncclGroupStart");
+        r.GroupEnd = (decltype(r.GroupEnd))sym("ncclGroupEnd");
+        r.Send = (decltype(r.Send))sym("ncclSend");
+        r.Recv = (decltype(r.Recv))sym("ncclRecv");
+        r.GetErrorString = (decltype(r.GetErrorString))sym("ncclGetErrorString");
+        r.GetVersion = (decltype(r.GetVersion))sym("ncclGetVersion");
+        if (!all) { dlclose(h); return; }
+        r.handle = h;
+    });
+    return r;
+}
+#define REEF_RCCL_TRY(call)                                                                           \
+    do {                                                                                              \
+        const ncclResult_t r_ = (call);                                                               \
+        if (r_ != ncclSuccess) { set_error("%s: %s", #call, rccl().GetErrorString(r_)); return REEF_ERR_HIP; } \
+    } while (0)
 
 // One persistent host thread per member: a call on the group hands every member its share and returns when all have ENQUEUED
 // (or, for rows, finished) theirs.  hipMemcpyAsync from the caller's pageable memory blocks the issuing thread while the runtime
@@ -90,6 +145,7 @@ struct Member {
     void *stage = nullptr;              // device-resident inputs of the caller live on devices[0]: this member's copy
     size_t stage_cap = 0;
     size_t off = 0, len = 0;            // points split: the slice [off, off + len) of the key
+    int rank = 0;                       // RCCL: the member's device as a rank of the group's communicator (member 0's device is rank 0)
 };
 
 }  // namespace
@@ -102,6 +158,8 @@ struct reef_msm_group {
     reef_jacobian *gather = nullptr;    // PEER: ndev slots on member 0's device; HOST: ndev slots of host-mapped pinned memory
     reef_jacobian *landing = nullptr;   // host-mapped: the sum lands here
     Workers *workers = nullptr;
+    std::vector<ncclComm_t> comms;      // RCCL: one communicator handle per distinct device, in order of first appearance in devices[]
+    std::vector<size_t> rank_lead;      // RCCL: the first member on each rank's device (its stream carries the rank's sends)
     std::mutex mu;                      // a group serialises its calls
 };
 
@@ -144,6 +202,7 @@ static reef_status member_fetch(reef_msm_group *g, Member &mb, const void *src, 
 // Where member i's partial sum goes, and -- after the call that computes it has been enqueued -- how it reaches member 0.
 static reef_jacobian *partial_target(reef_msm_group *g, size_t i) {
     Member &mb = g->m[i];
+    if (g->exchange == REEF_EXCHANGE_RCCL) return i == 0 ? g->gather : mb.partial;      // every other member sends, also to its own device
     if (g->exchange == REEF_EXCHANGE_HOST || mb.device == g->m[0].device) return g->gather + i;
     return mb.partial;
 }
@@ -152,7 +211,40 @@ static reef_status partial_send(reef_msm_group *g, size_t i) {
     if (g->exchange == REEF_EXCHANGE_PEER && mb.device != g->m[0].device)
         REEF_HIP_TRY(hipMemcpyPeerAsync(g->gather + i, g->m[0].device, mb.partial, mb.device, sizeof(reef_jacobian), mb.stream));
     if (g->exchange == REEF_EXCHANGE_PEER && i > 0) REEF_HIP_TRY(hipEventRecord(mb.done, mb.stream));
+    // RCCL: the sends of a rank ride on its leading member's stream (one stream per communicator inside a group call); the other
+    // members of the device hand over with an event
+    if (g->exchange == REEF_EXCHANGE_RCCL && i != g->rank_lead[(size_t)mb.rank]) REEF_HIP_TRY(hipEventRecord(mb.done, mb.stream));
     return REEF_OK;
+}
+// RCCL: all members have enqueued.  One group call: member i's 96 bytes go from its rank to rank 0's slot i.
+static reef_status rccl_gather(reef_msm_group *g) {
+    Rccl &R = rccl();
+    const size_t nd = g->m.size();
+    for (size_t i = 1; i < nd; ++i) {
+        Member &mb = g->m[i];
+        const size_t lead = g->rank_lead[(size_t)mb.rank];
+        if (lead == i) continue;
+        DevGuard dg(mb.device);
+        REEF_HIP_TRY(hipStreamWaitEvent(g->m[lead].stream, mb.done, 0));
+    }
+    REEF_RCCL_TRY(R.GroupStart());
+    reef_status st = REEF_OK;
+    for (size_t i = 1; i < nd && st == REEF_OK; ++i) {
+        Member &mb = g->m[i];
+        ncclResult_t r;
+        {
+            DevGuard dg(mb.device);
+            r = R.Send(mb.partial, sizeof(reef_jacobian), ncclUint8, 0, g->comms[(size_t)mb.rank], g->m[g->rank_lead[(size_t)mb.rank]].stream);
+        }
+        if (r == ncclSuccess) {
+            DevGuard dg(g->m[0].device);
+            r = R.Recv(g->gather + i, sizeof(reef_jacobian), ncclUint8, mb.rank, g->comms[0], g->m[0].stream);
+        }
+        if (r != ncclSuccess) { set_error("ncclSend/ncclRecv of member %zu: %s", i, R.GetErrorString(r)); st = REEF_ERR_HIP; }
+    }
+    const ncclResult_t e = R.GroupEnd();                 // closed whatever happened inside, or the thread stays in group mode
+    if (st == REEF_OK && e != ncclSuccess) { set_error("ncclGroupEnd: %s", R.GetErrorString(e)); st = REEF_ERR_HIP; }
+    return st;
 }
 // All members have enqueued: the partial sums are added on member 0's device and the result is waited for.
 static reef_status combine(reef_msm_group *g, reef_jacobian *out) {
@@ -166,6 +258,8 @@ static reef_status combine(reef_msm_group *g, reef_jacobian *out) {
             if (st == REEF_OK) st = w;
         }
         REEF_TRY(st);
+    } else if (g->exchange == REEF_EXCHANGE_RCCL) {
+        if (nd > 1) REEF_TRY(rccl_gather(g));
     } else {
         for (size_t i = 1; i < nd; ++i) REEF_HIP_TRY(hipStreamWaitEvent(m0.stream, g->m[i].done, 0));
     }
@@ -183,6 +277,10 @@ static reef_status combine(reef_msm_group *g, reef_jacobian *out) {
 static void group_free(reef_msm_group *g) {
     if (!g) return;
     delete g->workers;                                 // joins the member threads first
+    for (auto &mb : g->m)
+        if (mb.ctx) { DevGuard dg(mb.device); (void)reef_msm_ctx_sync(mb.ctx); }
+    for (ncclComm_t c : g->comms)
+        if (c) (void)rccl().CommDestroy(c);
     for (auto &mb : g->m) {
         DevGuard dg(mb.device);
         if (mb.ctx) (void)reef_msm_ctx_sync(mb.ctx);
@@ -227,7 +325,7 @@ reef_status reef_msm_group_create(reef_msm_group **out, int curve, const reef_af
     const uint32_t split = gopts ? gopts->split : (uint32_t)REEF_SPLIT_WINDOWS;
     uint32_t exchange = gopts ? gopts->exchange : (uint32_t)REEF_EXCHANGE_DEFAULT;
     if (split != REEF_SPLIT_WINDOWS && split != REEF_SPLIT_POINTS) { set_error("reef_msm_group_create: unknown split %u", split); return REEF_ERR_ARG; }
-    if (exchange > REEF_EXCHANGE_HOST) { set_error("reef_msm_group_create: unknown exchange %u", exchange); return REEF_ERR_ARG; }
+    if (exchange > REEF_EXCHANGE_RCCL) { set_error("reef_msm_group_create: unknown exchange %u", exchange); return REEF_ERR_ARG; }
     if (exchange == REEF_EXCHANGE_DEFAULT) exchange = REEF_EXCHANGE_PEER;
     for (size_t i = 0; i < ndev; ++i)
         if (devices[i] < 0) { set_error("reef_msm_group_create: devices[%zu] = %d", i, devices[i]); return REEF_ERR_ARG; }
@@ -235,6 +333,10 @@ reef_status reef_msm_group_create(reef_msm_group **out, int curve, const reef_af
     if (visible <= 0) { set_error("no HIP device visible"); return REEF_ERR_NO_GPU; }
     for (size_t i = 0; i < ndev; ++i)
         if (devices[i] >= visible) { set_error("reef_msm_group_create: devices[%zu] = %d, %d visible", i, devices[i], visible); return REEF_ERR_ARG; }
+    if (exchange == REEF_EXCHANGE_RCCL && !rccl().ok()) {
+        set_error("reef_msm_group_create: REEF_EXCHANGE_RCCL asked for and RCCL cannot be loaded: %s", rccl().why);
+        return REEF_ERR_HIP;
+    }
     return guarded([&]() -> reef_status {
         reef_msm_group *g = new reef_msm_group();
         g->curve = curve; g->split = split; g->exchange = exchange; g->n = n;
@@ -246,6 +348,9 @@ reef_status reef_msm_group_create(reef_msm_group **out, int curve, const reef_af
                 mb.device = devices[i];
                 bool first_on_device = true;
                 for (size_t j = 0; j < i; ++j) first_on_device = first_on_device && devices[j] != devices[i];
+                if (first_on_device) g->rank_lead.push_back(i);
+                for (size_t r = 0; r < g->rank_lead.size(); ++r)
+                    if (devices[g->rank_lead[r]] == devices[i]) mb.rank = (int)r;
                 g->distinct += first_on_device;
                 DevGuard dg(mb.device);
                 reef_msm_opts o = {};
@@ -297,8 +402,8 @@ reef_status reef_msm_group_create(reef_msm_group **out, int curve, const reef_af
                 mb.stream = (hipStream_t)reef_msm_ctx_stream(mb.ctx);
                 if (!mb.stream) { set_error("reef_msm_group_create: member %zu got no stream", i); return REEF_ERR_HIP; }
                 REEF_HIP_TRY(hipEventCreateWithFlags(&mb.done, hipEventDisableTiming));
+                if (mb.device != dev0 || (exchange == REEF_EXCHANGE_RCCL && i > 0)) REEF_HIP_TRY(hipMalloc((void **)&mb.partial, sizeof(reef_jacobian)));
                 if (mb.device != dev0) {
-                    REEF_HIP_TRY(hipMalloc((void **)&mb.partial, sizeof(reef_jacobian)));
                     int can = 0;
                     if (hipDeviceCanAccessPeer(&can, mb.device, dev0) == hipSuccess && can) {
                         const hipError_t e = hipDeviceEnablePeerAccess(dev0, 0);
@@ -314,6 +419,12 @@ reef_status reef_msm_group_create(reef_msm_group **out, int curve, const reef_af
                 if (exchange == REEF_EXCHANGE_HOST) REEF_HIP_TRY(hipHostMalloc((void **)&g->gather, ndev * sizeof(reef_jacobian), hipHostMallocPortable | hipHostMallocMapped));
                 else REEF_HIP_TRY(hipMalloc((void **)&g->gather, ndev * sizeof(reef_jacobian)));
                 REEF_HIP_TRY(hipHostMalloc((void **)&g->landing, sizeof(reef_jacobian), hipHostMallocPortable | hipHostMallocMapped));
+            }
+            if (exchange == REEF_EXCHANGE_RCCL) {
+                std::vector<int> devlist;
+                for (size_t lead : g->rank_lead) devlist.push_back(devices[lead]);
+                g->comms.assign(devlist.size(), nullptr);
+                REEF_RCCL_TRY(rccl().CommInitAll(g->comms.data(), (int)devlist.size(), devlist.data()));
             }
             if (ndev > 1) g->workers = new Workers(ndev);
             return REEF_OK;

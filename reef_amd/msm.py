@@ -274,7 +274,7 @@ class MsmContext:
 
 
 SPLIT_WINDOWS, SPLIT_POINTS = 0, 1
-EXCHANGE_PEER, EXCHANGE_HOST = 1, 2
+EXCHANGE_PEER, EXCHANGE_HOST, EXCHANGE_RCCL = 1, 2, 3
 
 
 class MsmGroup:
@@ -303,7 +303,7 @@ class MsmGroup:
         gi = _ffi.GroupInfo()
         check(self._lib.reef_msm_group_info_get(self._h, ctypes.byref(gi)))
         return {"members": gi.members, "distinct_devices": gi.distinct_devices, "split": ("windows", "points")[gi.split],
-                "exchange": {1: "peer", 2: "host-staged"}[gi.exchange], "peer_members": gi.peer_members,
+                "exchange": {1: "peer", 2: "host-staged", 3: "rccl"}[gi.exchange], "peer_members": gi.peer_members,
                 "key_points": list(gi.key_points[:min(gi.members, 16)])}
 
     def msm(self, scalars: Buf, n: Optional[int] = None, *, is_mont: bool = True) -> np.ndarray:

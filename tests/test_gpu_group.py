@@ -28,7 +28,8 @@ def key(cref):
 @pytest.mark.parametrize("split", ["windows", "points"])
 @pytest.mark.parametrize("name", ["pallas", "vesta"])
 def test_group_msm_equals_the_oracle(name, split, members, gpu_lib, cref, key):
-    """One MSM over a group of 1 / 2 / 3 / 8 members on device 0, both splits, both curves, both exchanges; host and device
+    """One MSM over a group of 1 / 2 / 3 / 8 members on device 0, both splits, both curves, the three exchanges (RCCL: a one-rank communicator, every member but
+    member 0 sends its partial sum to its own rank); host and device
     scalars; prefixes of the key (n < key length, n smaller than the member count, n = 0); both scalar conventions."""
     from reef_amd import msm
     cid = CURVE[name]
@@ -40,11 +41,11 @@ def test_group_msm_equals_the_oracle(name, split, members, gpu_lib, cref, key):
     canon = cref.gen_scalars(cid, 55 + members, n, kind=0, mont=False)
     want = cref.compress(cid, cref.msm_pippenger(cid, bases, sc, threads=4))
     want_w = cref.compress(cid, cref.msm_pippenger(cid, bases, sc_w, threads=4))
-    for exchange in (msm.EXCHANGE_PEER, msm.EXCHANGE_HOST):
+    for exchange in (msm.EXCHANGE_PEER, msm.EXCHANGE_HOST, msm.EXCHANGE_RCCL):
         with msm.MsmGroup(cid, bases, [0] * members, split=sp, exchange=exchange) as g:
             info = g.info()
             assert info["members"] == members and info["distinct_devices"] == 1 and info["split"] == split
-            assert info["exchange"] == ("peer" if exchange == msm.EXCHANGE_PEER else "host-staged")
+            assert info["exchange"] == {msm.EXCHANGE_PEER: "peer", msm.EXCHANGE_HOST: "host-staged", msm.EXCHANGE_RCCL: "rccl"}[exchange]
             if split == "points":
                 assert sum(info["key_points"]) == n and max(info["key_points"]) - min(info["key_points"]) <= 1
             else:
@@ -112,6 +113,48 @@ def test_group_rows_dealt_out_whole(members, gpu_lib, cref, key):
         with pytest.raises(msm.ReefError) as e:
             g.msm_rows(cref.gen_scalars(cid, 1, 20), 2, 10)
         assert e.value.status == 1 and "REEF_SPLIT_WINDOWS" in str(e.value)
+
+
+def test_group_rccl_exchange_runs_in_a_process_of_its_own_and_fails_loudly_without_the_library(cref, tmp_path):
+    """REEF_EXCHANGE_RCCL in a fresh process (RCCL is opened once per process): one commitment with a blind and one MSM over three
+    members, both splits, against the C oracle; and with REEF_RCCL_LIB pointing nowhere the group's creation fails with the
+    loader's message (status 2) -- no fallback to another exchange."""
+    import os
+    import subprocess
+    import sys
+    cid, n = 0, 3000
+    bases = cref.gen_bases_ap(cid, 321, 7, n)
+    sc = cref.gen_scalars(cid, 17, n)
+    b = cref.gen_scalars(cid, 18, 1)
+    h = cref.gen_bases_ap(cid, 0xB11D, 1, 1)[0].copy()
+    want = cref.compress(cid, cref.msm_pippenger(cid, bases, sc, threads=4)).hex()
+    want_b = cref.compress(cid, cref.row_msm(cid, bases, sc, 1, n, h=h, blinds=b, threads=4)).hex()
+    np.savez(tmp_path / "in.npz", bases=bases, sc=sc, b=b, h=h)
+    code = f"""
+import numpy as np, sys
+from reef_amd import msm
+d = np.load(r'{tmp_path / "in.npz"}')
+try:
+    for sp in (msm.SPLIT_WINDOWS, msm.SPLIT_POINTS):
+        with msm.MsmGroup(0, d['bases'], [0, 0, 0], split=sp, exchange=msm.EXCHANGE_RCCL) as g:
+            assert g.info()['exchange'] == 'rccl'
+            for rep in range(3):
+                print('msm', msm.compress(0, g.msm(d['sc'])).hex())
+            if sp == msm.SPLIT_WINDOWS:
+                print('blind', msm.compress(0, g.msm_rows(d['sc'], 1, {n}, blinds=d['b'], h=d['h'])).hex())
+except msm.ReefError as e:
+    print('error', e.status, str(e))
+"""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, PYTHONPATH=root)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, env=env, cwd=root)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = r.stdout.split("\n")
+    assert [l for l in lines if l.startswith("msm ")] == ["msm " + want] * 6, r.stdout + r.stderr[-1500:]
+    assert [l for l in lines if l.startswith("blind ")] == ["blind " + want_b], r.stdout
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, env=dict(env, REEF_RCCL_LIB="/nonexistent/librccl.so"), cwd=root)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert r.stdout.startswith("error 2 ") and "REEF_EXCHANGE_RCCL" in r.stdout and "/nonexistent/librccl.so" in r.stdout, r.stdout
 
 
 def test_group_at_the_headline_size_dlog_property(gpu_lib):

@@ -60,6 +60,8 @@ def test_bench_with_two_ranks(sharding, logn, gpu_lib):
         sp = ss["single_process"]                              # round 5: the same devices driven by ONE process through reef_msm_group_* (a child of rank 0)
         assert sp["check"] == "dlog-ok" and sp["devices"] == [0, 0] and sp["exchange"].startswith("peer") and sp["value"] > 0
         assert sp["strong_scaling"]["windows_ms_per_step"] > 0 and sp["strong_scaling"]["points_ms_per_step"] > 0
+        spr = ss["single_process_rccl"]                        # and with the partial sums as ncclSend/ncclRecv on a single-process communicator
+        assert spr["check"] == "dlog-ok" and spr["exchange"].startswith("rccl") and spr["value"] > 0 and spr["strong_scaling"]["windows_ms_per_step"] > 0
         assert set(ss["speedup_vs_1"]) == {"windows", "points"} and ss["one_gpu_ms_per_msm"] == pytest.approx(cfg["ms_per_msm"]) and cfg["msms_per_step"] == 256 \
             and line["ms_per_step"] == pytest.approx(256 * cfg["ms_per_msm"])
     else:
@@ -77,13 +79,13 @@ def test_world_size_must_match_gpus(gpu_lib):
     assert out.returncode != 0 and "WORLD_SIZE=2" in out.stderr
 
 
-@pytest.mark.parametrize("members,logn", [(2, 16), (8, 14), (3, 17)])
-def test_bench_single_process_over_a_device_group(members, logn, gpu_lib):
+@pytest.mark.parametrize("members,logn,exchange", [(2, 16, "peer"), (8, 14, "peer"), (3, 17, "peer"), (3, 14, "rccl"), (2, 14, "host")])
+def test_bench_single_process_over_a_device_group(members, logn, exchange, gpu_lib):
     """`bench.py --gpus N --single-process`: no launcher, no torch -- ONE process drives N members through reef_msm_group_* (what a Rust
     prover can call; Reef is one process, src/backend/main.rs:82).  On a one-GPU box the ordinals repeat device 0 and the line says
     that it is not a scaling measurement; every combined point is checked against its discrete logarithm."""
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(members), "--single-process", "--logn", str(logn), "--steps", "3", "--warmup", "1",
-           "--msms-per-step", "6"]
+           "--msms-per-step", "6", "--group-exchange", exchange]
     out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT)
     assert out.returncode == 0, out.stderr[-3000:]
     lines = [ln for ln in out.stdout.strip().splitlines() if ln.startswith("{")]
@@ -93,7 +95,7 @@ def test_bench_single_process_over_a_device_group(members, logn, gpu_lib):
     assert line["n_gpus"] == members and cfg["check"] == "dlog-ok" and line["scaling"] == "weak"
     assert cfg["mode"].startswith("single-process") and cfg["devices"] == [0] * members and cfg["distinct_devices"] == 1
     assert "NOT a scaling measurement" in cfg["devices_note"] if members > 1 else cfg["devices_note"] is None
-    assert cfg["exchange"].startswith("peer") and cfg["total_points"] == members << logn
+    assert cfg["exchange"].startswith({"peer": "peer", "rccl": "rccl", "host": "host-staged"}[exchange]) and cfg["total_points"] == members << logn
     assert sum(cfg["key_points_per_member"]) == members << logn
     ss = cfg["strong_scaling"]
     assert ss["one_msm_points"] == 1 << logn and set(ss["speedup_vs_1"]) == {"windows", "points"}

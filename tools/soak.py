@@ -53,7 +53,7 @@ while time.time() < t_end:
             bases[rng.integers(0, n, size=2)] = 0
         sc = R.gen_scalars(cid, int(rng.integers(1, 1 << 30)), n, kind=int(rng.integers(0, 2)))
         split = int(rng.integers(0, 2))
-        with msm.MsmGroup(cid, bases, devs, split=split, exchange=int(rng.choice([1, 2])), bucket_groups=int(rng.choice([0, 1, 1]))) as g:
+        with msm.MsmGroup(cid, bases, devs, split=split, exchange=int(rng.choice([1, 2, 3])), bucket_groups=int(rng.choice([0, 1, 1]))) as g:
             m = int(rng.integers(0, n + 1)) if rng.random() < 0.3 else n
             want = R.compress(cid, R.msm_pippenger(cid, bases[:m].copy(), sc[:m].copy(), threads=16)) if m else bytes(32)
             buf = sc[:m].copy() if m else np.zeros((0, 4), np.uint64)

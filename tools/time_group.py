@@ -34,7 +34,7 @@ def main():
             print(f"2^{logn} one context: device scalars %.3f ms (min %.3f max %.3f), host scalars %.3f ms" % (*med(lambda: c.msm(dsc, n)), med(lambda: c.msm(hsc))[0]))
         for members in (1, 2, 4, 8):
             for name, sp in (("windows", msm.SPLIT_WINDOWS), ("points", msm.SPLIT_POINTS)):
-                for ex in (msm.EXCHANGE_PEER, msm.EXCHANGE_HOST):
+                for ex in (msm.EXCHANGE_PEER, msm.EXCHANGE_HOST, msm.EXCHANGE_RCCL):
                     with msm.MsmGroup("pallas", bases, [i % vis for i in range(members)], n, split=sp, exchange=ex) as g:
                         a = med(lambda: g.msm(dsc, n))
                         b = med(lambda: g.msm(hsc))
