@@ -525,6 +525,33 @@ def single_process_main(a):
         strong["hyrax_rows"] = {"rows": h_rows, "row_len": h_len, "symbol_bits": h_bits, "ms_per_commit": h_ms, "check": "dlog-ok" if rows_ok else "MISMATCH",
                                 "note": "HyraxPC::commit of a 16 MiB DNA document from host bytes, rows dealt out in contiguous blocks to the members, results written "
                                         "straight into the caller's array (PCIe-inclusive)"}
+    # independent units: configs[4]'s --merkle commitment, the Poseidon tree in blocks over the devices (stand-in constants: timing and equality
+    # with one device's root; hash parity is tests/test_gpu_merkle.py)
+    if a.logn >= 16:
+        from reef_amd import merkle
+        # the permutation's constants are the caller's (neptune's, on the Rust side); here: seeded round constants and a Cauchy matrix 1 / (i + 5 + j) over
+        # Pallas' scalar field, width 5, 8 full and 56 partial rounds (the shape of neptune's U4 instance)
+        FQ = 0x40000000000000000000000000000000224698fc0994a8dd8c46eb2100000001
+        prng = np.random.default_rng(0x9051D0)
+        m_rc = [int.from_bytes(prng.bytes(40), "little") % FQ for _ in range(5 * (8 + 56))]
+        m_mds = [[pow(i + 5 + j, -1, FQ) for j in range(5)] for i in range(5)]
+        mlog = 24
+        mdoc = np.random.default_rng(0x3E2C).integers(0, 256, size=1 << mlog, dtype=np.uint32)
+        margs = ("pallas", mdoc, 5, 8, 56, m_rc, m_mds, 4 << 32 | 1, 2 << 32 | 1)
+        root1, _ = merkle.commit_arrays(*margs, want_tree=False)
+        t0 = time.perf_counter()
+        root1, _ = merkle.commit_arrays(*margs, want_tree=False)
+        one_ms = (time.perf_counter() - t0) * 1e3
+        minfo = {}
+        rootd, _ = merkle.commit_arrays(*margs, want_tree=False, devices=devices, info=minfo)
+        t0 = time.perf_counter()
+        rootd, _ = merkle.commit_arrays(*margs, want_tree=False, devices=devices, info=minfo)
+        dev_ms = (time.perf_counter() - t0) * 1e3
+        check_ok = check_ok and rootd == root1
+        strong["merkle_commit"] = {"symbols": 1 << mlog, "blocks": minfo.get("blocks"), "ms_per_commit": dev_ms, "one_device_ms_per_commit": one_ms,
+                                   "check": "same-root" if rootd == root1 else "MISMATCH",
+                                   "note": "MerkleCommitment::new (merkle_tree.rs:25-80) of a 2^24-symbol document from host memory, the bottom level cut into power-of-two "
+                                           "blocks, one per device, the levels above hashed from the blocks' roots on devices[0]; root returned (PCIe-inclusive)"}
     value = N * n * a.steps * MPS / elapsed
     achieved = BYTES_PER_PAIR * n / (acc_ms * 1e-3) / 1e9 if acc_ms > 0 else None
     out = {"metric": "msm_scalar_point_pairs_per_sec", "value": value, "unit": "pairs/s", "n_gpus": N, "steps": a.steps, "warmup": a.warmup,

@@ -23,7 +23,7 @@
  * ABI changelog (reef_abi_version()):
  *   5  round 5: device groups (reef_msm_group_*: one MSM split by window or by points, or the rows of a Hyrax commitment dealt out
  *      whole, over several GPUs of ONE process, the partial sums exchanged inside the library: peer copies, host slots, or a
- *      single-process RCCL communicator loaded at run time); reef_get_device;
+ *      single-process RCCL communicator loaded at run time); reef_merkle_commit_devices (the Merkle tree in blocks over several GPUs); reef_get_device;
  *      reef_key_cache_timing_get; reef_runtime_opts.hw_queues is the only way the library touches GPU_MAX_HW_QUEUES unless
  *      REEF_MSM_HW_QUEUES is exported (the load-time default of rounds 3-4 is gone); the drop-in symbols confirm a returning key's
  *      bytes on the host whatever its size (no key upload on a hit).
@@ -342,6 +342,16 @@ typedef struct {
 uint64_t reef_merkle_nodes(uint64_t n);
 reef_status reef_merkle_commit(int curve, const reef_poseidon_params *params, const uint32_t *doc, size_t n, int doc_loc,
                                bool is_mont, reef_fe *tree_out, int tree_loc, reef_fe *root_out);
+/* The same tree built by several GPUs of ONE process (BASELINE configs[4]: the 64 MiB --merkle document on 8 GPUs; SURVEY.md 8e.1:
+ * independent units).  The bottom level is cut into blocks of 2^L nodes -- the smallest L that leaves at most ndev blocks -- and block b is
+ * hashed by devices[b] on a host thread of its own: a block is a subtree of the whole tree (its leaf hashes take the symbols' positions in
+ * the whole document; a ragged last block keeps hashing (node, 0) up to level L as the whole tree does), so the devices exchange nothing
+ * but their block's root, 32 bytes each, through the host; the levels above L are hashed from those roots on devices[0].  doc, tree_out
+ * (may be NULL) and root_out (may be NULL, not both) are HOST memory: every device reads its slice of the document and writes its slices of
+ * the levels over its own PCIe link.  Node for node the tree of reef_merkle_commit.  *blocks_out (may be NULL): how many blocks, hence
+ * devices, the call used (a power-of-two cut: 3 devices and 2^26 bottom nodes give 2 blocks).  devices[] may repeat an ordinal. */
+reef_status reef_merkle_commit_devices(int curve, const reef_poseidon_params *params, const uint32_t *doc, size_t n, bool is_mont,
+                                       const int *devices, size_t ndev, reef_fe *tree_out, reef_fe *root_out, uint32_t *blocks_out);
 
 /* ---------------------------------------------------------------------------------------------
  * (3e) Row N1: derivation of a commitment key from a label.

@@ -149,6 +149,7 @@ def load() -> ctypes.CDLL:
         "reef_sc_sync": (c_int, [vp]),
         "reef_merkle_nodes": (c_uint64, [c_uint64]),
         "reef_merkle_commit": (c_int, [c_int, vp, vp, c_size_t, c_int, c_bool, vp, c_int, vp]),
+        "reef_merkle_commit_devices": (c_int, [c_int, vp, vp, c_size_t, c_bool, vp, c_size_t, vp, vp, vp]),
         "reef_derive_generators": (c_int, [c_int, vp, c_size_t, c_size_t, vp, c_bool, vp, c_int]),
         "reef_shake256": (None, [vp, c_size_t, vp, c_size_t]),
         "reef_test_field_op": (c_int, [c_int, c_int, vp, vp, vp, c_size_t]),

@@ -2,6 +2,7 @@
 // no arithmetic here and no CPU fallback: without a gfx950 device every call fails loudly.
 #include <stdarg.h>
 #include <stdio.h>
+#include <string>
 #include <vector>
 #include <new>
 #include <exception>
@@ -429,7 +430,92 @@ reef_status reef_merkle_commit(int curve, const reef_poseidon_params *params, co
     const CurveVTable *v = vt(curve);
     if (!v) return REEF_ERR_ARG;
     REEF_TRY(require_gpu());
-    return guarded([&] { return v->merkle_commit(params, doc, n, doc_loc, is_mont, tree_out, tree_loc, root_out); });
+    return guarded([&] { return v->merkle_commit(params, doc, n, doc_loc, is_mont, tree_out, tree_loc, root_out, nullptr); });
+}
+
+// The same tree built by several devices of this process (include/reef_msm.h 5b).  The bottom level is cut into blocks of S = 2^L nodes, one
+// block per device; a block is a subtree of the whole tree, so the devices exchange nothing but their block's root (32 bytes each, through the
+// host), and the levels above L are hashed from those roots on devices[0].
+reef_status reef_merkle_commit_devices(int curve, const reef_poseidon_params *params, const uint32_t *doc, size_t n, bool is_mont, const int *devices,
+                                       size_t ndev, reef_fe *tree_out, reef_fe *root_out, uint32_t *blocks_out) {
+    const CurveVTable *v = vt(curve);
+    if (!v) return REEF_ERR_ARG;
+    if (!devices || ndev == 0 || ndev > 64) { set_error("reef_merkle_commit_devices: devices"); return REEF_ERR_ARG; }
+    if (!params || (n && !doc) || (!tree_out && !root_out)) { set_error("null argument"); return REEF_ERR_ARG; }
+    if (n == 0 || n >= (1ull << 33)) { set_error("document length out of range"); return REEF_ERR_ARG; }
+    REEF_TRY(require_gpu());
+    const int visible = reef_device_count();
+    for (size_t i = 0; i < ndev; ++i)
+        if (devices[i] < 0 || devices[i] >= visible) { set_error("reef_merkle_commit_devices: devices[%zu] = %d, %d visible", i, devices[i], visible); return REEF_ERR_ARG; }
+    return guarded([&]() -> reef_status {
+        // global shape of the tree: sizes and offsets of its levels (merkle_tree.rs:25-80)
+        std::vector<uint64_t> size, off;
+        {
+            uint64_t m = ((uint64_t)n + 1) / 2, o = 0;
+            for (;;) {
+                size.push_back(m); off.push_back(o);
+                o += m;
+                if (m <= 1) break;
+                m = (m + 1) / 2;
+            }
+        }
+        uint32_t L = 0;                                    // block height: the smallest power of two with at most ndev blocks
+        while (((size[0] + (1ull << L) - 1) >> L) > ndev) ++L;
+        const uint64_t S = 1ull << L;
+        const size_t nb = (size_t)((size[0] + S - 1) / S);
+        if (blocks_out) *blocks_out = (uint32_t)nb;
+        struct DeviceScope {
+            int prev = -1;
+            explicit DeviceScope(int d) { (void)hipGetDevice(&prev); (void)hipSetDevice(d); }
+            ~DeviceScope() { if (prev >= 0) (void)hipSetDevice(prev); }
+        };
+        if (nb == 1) {
+            DeviceScope ds(devices[0]);
+            return v->merkle_commit(params, doc, n, REEF_HOST, is_mont, tree_out, REEF_HOST, root_out, nullptr);
+        }
+        std::vector<reef_fe> roots(nb);
+        std::vector<reef_status> st(nb, REEF_OK);
+        std::vector<std::string> msg(nb);
+        std::vector<std::thread> th;
+        for (size_t b = 0; b < nb; ++b)
+            th.emplace_back([&, b] {
+                DeviceScope ds(devices[b]);
+                MerkleSlice sl;
+                sl.index_base = 2 * b * S;
+                sl.levels = L;
+                std::vector<reef_fe *> dst(L + 1, nullptr);
+                if (tree_out)
+                    for (uint32_t h = 0; h <= L; ++h) dst[h] = tree_out + off[h] + ((b * S) >> h);
+                sl.level_out = dst.data();
+                sl.top_out = &roots[b];
+                const uint64_t first = 2 * b * S, cnt = std::min<uint64_t>((uint64_t)n - first, 2 * S);
+                try {
+                    st[b] = v->merkle_commit(params, doc + first, (size_t)cnt, REEF_HOST, is_mont, nullptr, REEF_HOST, nullptr, &sl);
+                } catch (const std::exception &e) {
+                    set_error("internal error: %s", e.what());
+                    st[b] = REEF_ERR_HIP;
+                }
+                if (st[b] != REEF_OK) msg[b] = reef_last_error();
+            });
+        for (auto &t : th) t.join();
+        for (size_t b = 0; b < nb; ++b)
+            if (st[b] != REEF_OK) { set_error("block %zu (device %d): %s", b, devices[b], msg[b].c_str()); return st[b]; }
+        // the levels above the blocks, from their roots
+        MerkleSlice top;
+        top.nodes_in = roots.data();
+        top.nodes_n = nb;
+        top.levels = (uint32_t)(size.size() - 1 - L);
+        std::vector<reef_fe *> dst(top.levels + 1, nullptr);
+        if (tree_out)
+            for (uint32_t h = 1; h <= top.levels; ++h) dst[h] = tree_out + off[L + h];    // level L itself is the blocks' own
+        top.level_out = dst.data();
+        reef_fe root;
+        top.top_out = &root;
+        DeviceScope ds(devices[0]);
+        REEF_TRY(v->merkle_commit(params, nullptr, 0, REEF_HOST, is_mont, nullptr, REEF_HOST, nullptr, &top));
+        if (root_out) *root_out = root;
+        return REEF_OK;
+    });
 }
 
 reef_status reef_derive_generators(int curve, const uint8_t *label, size_t label_len, size_t n, const reef_keygen_params *params, bool is_mont,

@@ -212,6 +212,19 @@ struct StreamLease {
 };
 
 // Per-curve entry points, implemented once per curve in kernels_<curve>.hip via engine.inc.
+// One block of a Merkle tree built by several devices: the subtree over the document symbols [index_base, index_base + n) carried up exactly
+// `levels` levels above its bottom level (a ragged last block keeps hashing (node, 0) where the whole tree would: merkle_tree.rs:82-114), or --
+// nodes_in != NULL -- the levels above a given bottom level (the blocks' roots).  level_out[h], h = 0..levels: where level h of the block goes
+// (HOST memory, the caller's form; entries may be NULL); top_out: the first node of the last level (host).
+struct MerkleSlice {
+    uint64_t index_base = 0;
+    uint32_t levels = 0;
+    const reef_fe *nodes_in = nullptr;   // host, nodes_n of them, in the caller's form
+    size_t nodes_n = 0;
+    reef_fe *const *level_out = nullptr;
+    reef_fe *top_out = nullptr;
+};
+
 struct CurveVTable {
     reef_status (*ctx_create)(void **impl, const reef_affine *bases, size_t n, int loc, const reef_msm_opts *opts);
     reef_status (*ctx_rekey)(void *impl, const reef_affine *bases, size_t n, int loc);
@@ -258,9 +271,10 @@ struct CurveVTable {
     // row N3: bound rows / evaluation of a multilinear table over the curve's scalar field
     reef_status (*mle_bound)(const void *z, size_t n, int elem_bytes, int z_loc, bool is_mont, const reef_fe *point, size_t num_vars,
                              size_t left_vars, reef_fe *lz_out, int out_loc, reef_fe *eval_out);
-    // row N4: Poseidon Merkle commitment over the curve's scalar field
+    // row N4: Poseidon Merkle commitment over the curve's scalar field.  slice (may be NULL: the whole tree of a document): one block of a tree that
+    // several devices build together (reef_merkle_commit_devices, api.cpp)
     reef_status (*merkle_commit)(const reef_poseidon_params *pp, const uint32_t *doc, size_t n, int doc_loc, bool is_mont, reef_fe *tree_out,
-                                 int out_loc, reef_fe *root_out);
+                                 int out_loc, reef_fe *root_out, const struct MerkleSlice *slice);
     // row N1: commitment-key derivation (hash to the curve; coordinates in the curve's base field)
     reef_status (*derive_generators)(const uint8_t *label, size_t label_len, size_t n, const reef_keygen_params *kp, bool is_mont, reef_affine *out,
                                      int out_loc);

@@ -422,6 +422,27 @@ static std::string replay_devices(const Shape &shape, const std::vector<int> &or
         CK(reef_normalize(REEF_PALLAS, out_1.data(), rows, REEF_HOST, a1.data(), nullptr));
         if (memcmp(ag.data(), a1.data(), rows * sizeof(reef_affine)) != 0) fail("reef_replay: the group's row commitments differ from one device's");
     }
+    // --merkle: the Poseidon tree of the document in blocks over the devices (reef_merkle_commit_devices), root against one device's
+    double merkle_devices_ms = 0, merkle_one_ms = 0;
+    uint32_t merkle_blocks = 0;
+    if (sh->merkle_log) {
+        const size_t n_doc = (size_t)1 << sh->merkle_log;
+        std::vector<uint32_t> doc(n_doc);
+        for (size_t i = 0; i < n_doc; ++i) doc[i] = (uint32_t)((i * 2654435761u) >> 24);
+        reef_poseidon_params pp;
+        pp.width = 5; pp.full_rounds = STANDIN_POSEIDON_RF; pp.partial_rounds = STANDIN_POSEIDON_RP; pp.reserved = 0;
+        pp.round_constants = STANDIN_POSEIDON_RC; pp.mds = STANDIN_POSEIDON_MDS;
+        pp.tag_leaf = STANDIN_POSEIDON_TAGS[0]; pp.tag_node = STANDIN_POSEIDON_TAGS[1];
+        reef_fe root_d, root_1;
+        CK(reef_merkle_commit_devices(REEF_PALLAS, &pp, doc.data(), (size_t)1 << 16, false, ordinals.data(), nd, nullptr, &root_d, nullptr));      // warm-up
+        auto t0 = clk::now();
+        CK(reef_merkle_commit_devices(REEF_PALLAS, &pp, doc.data(), n_doc, false, ordinals.data(), nd, nullptr, &root_d, &merkle_blocks));
+        merkle_devices_ms = ms_since(t0);
+        t0 = clk::now();
+        CK(reef_merkle_commit(REEF_PALLAS, &pp, doc.data(), n_doc, REEF_HOST, false, nullptr, REEF_HOST, &root_1));
+        merkle_one_ms = ms_since(t0);
+        if (memcmp(&root_d, &root_1, sizeof root_1) != 0) fail("reef_replay: the Merkle commitment built in blocks differs from one device's");
+    }
     double sum_alone = 0, longest = 0;
     for (Arg &a : args) { sum_alone += a.alone_ms; longest = std::max(longest, a.alone_ms); }
     std::string placed = "[";
@@ -435,9 +456,11 @@ static std::string replay_devices(const Shape &shape, const std::vector<int> &or
     snprintf(line.data(), line.size(), "{\"members\": %zu, \"distinct_devices\": %zu, \"visible_devices\": %d, \"note\": \"one process: the final SNARK's arguments placed whole on the devices "
              "(per-device contexts, one caller thread each), the document commitment through a device group; ordinals repeat when the box has fewer GPUs than members\", "
              "\"final_snark_placed\": %s, \"three_arguments_one_after_the_other_ms\": %.3f, \"three_arguments_on_devices_ms\": %.3f, \"longest_argument_ms\": %.3f, "
-             "\"commit_hyrax_group_ms\": %.3f, \"commit_hyrax_one_device_ms\": %.3f, \"commit_rows_checked_against_one_device\": %s, \"group_exchange\": \"%s\", \"group_peer_members\": %u}",
+             "\"commit_hyrax_group_ms\": %.3f, \"commit_hyrax_one_device_ms\": %.3f, \"commit_rows_checked_against_one_device\": %s, \"group_exchange\": \"%s\", \"group_peer_members\": %u, "
+             "\"commit_merkle_devices_ms\": %.3f, \"commit_merkle_one_device_ms\": %.3f, \"commit_merkle_blocks\": %u, \"commit_merkle_root_checked_against_one_device\": %s}",
              nd, uniq.size(), reef_device_count(), placed.c_str(), sum_alone, together_ms, longest, commit_group_ms, commit_one_ms, sh->doc_log ? "true" : "false",
-             gi.exchange == REEF_EXCHANGE_HOST ? "host-staged" : "peer copies (hipMemcpyPeerAsync; in place on a shared device)", gi.peer_members);
+             gi.exchange == REEF_EXCHANGE_HOST ? "host-staged" : "peer copies (hipMemcpyPeerAsync; in place on a shared device)", gi.peer_members,
+             merkle_devices_ms, merkle_one_ms, merkle_blocks, sh->merkle_log ? "true" : "false");
     return std::string(line.data());
 }
 

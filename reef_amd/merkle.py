@@ -4,7 +4,7 @@ side); this module only marshals them."""
 from __future__ import annotations
 
 import ctypes
-from typing import List, Sequence, Tuple
+from typing import Optional, List, Sequence, Tuple
 
 import numpy as np
 
@@ -50,9 +50,11 @@ def commit(curve, doc: Sequence[int], width: int, full_rounds: int, partial_roun
 
 
 def commit_arrays(curve, doc: np.ndarray, width: int, full_rounds: int, partial_rounds: int, round_constants: Sequence[int],
-                  mds: Sequence[Sequence[int]], tag_leaf: int, tag_node: int, want_tree: bool = True) -> Tuple[int, List[np.ndarray]]:
+                  mds: Sequence[Sequence[int]], tag_leaf: int, tag_node: int, want_tree: bool = True,
+                  devices: Optional[Sequence[int]] = None, info: Optional[dict] = None) -> Tuple[int, List[np.ndarray]]:
     """The same call for documents too large for Python integers: -> (commitment, levels as (m, 4) uint64 arrays of canonical
-    limbs, level 0 first; empty when want_tree is False and only the root is copied back)."""
+    limbs, level 0 first; empty when want_tree is False and only the root is copied back).  devices: the tree in blocks over
+    several GPUs of this process (reef_merkle_commit_devices; ordinals may repeat); info["blocks"] says how many blocks it took."""
     lib = _ffi.load()
     rc = ints_to_array(list(round_constants))
     m = ints_to_array([x for row in mds for x in row])
@@ -64,8 +66,16 @@ def commit_arrays(curve, doc: np.ndarray, width: int, full_rounds: int, partial_
     total = nodes(n)
     tree = np.empty((total, 4), dtype=np.uint64) if want_tree else None
     root = np.zeros((1, 4), dtype=np.uint64)
-    check(lib.reef_merkle_commit(curve_id(curve), ctypes.byref(pp), d.ctypes.data, n, REEF_HOST, False, tree.ctypes.data if want_tree else None, REEF_HOST,
-                                 root.ctypes.data))
+    if devices is None:
+        check(lib.reef_merkle_commit(curve_id(curve), ctypes.byref(pp), d.ctypes.data, n, REEF_HOST, False, tree.ctypes.data if want_tree else None, REEF_HOST,
+                                     root.ctypes.data))
+    else:
+        devs = (ctypes.c_int * len(devices))(*devices)
+        blocks = ctypes.c_uint32(0)
+        check(lib.reef_merkle_commit_devices(curve_id(curve), ctypes.byref(pp), d.ctypes.data, n, False, devs, len(devices), tree.ctypes.data if want_tree else None,
+                                             root.ctypes.data, ctypes.byref(blocks)))
+        if info is not None:
+            info["blocks"] = blocks.value
     levels: List[np.ndarray] = []
     if want_tree:
         m_, off = (n + 1) // 2, 0

@@ -125,6 +125,13 @@ def test_struct_sizes_of_the_group_api_and_its_argument_errors():
     assert lib.reef_msm_group_msm(None, None, 0, 0, True, None) == 1
     assert lib.reef_msm_group_info_get(None, None) == 1
     lib.reef_msm_group_destroy(None)                                # a no-op
+    # the Merkle tree in blocks over several devices: argument errors before any device is touched
+    doc = np.arange(8, dtype=np.uint32)
+    root = np.zeros(4, dtype=np.uint64)
+    assert lib.reef_merkle_commit_devices(0, None, doc.ctypes.data, 8, False, devs, 2, None, root.ctypes.data, None) == 1
+    assert lib.reef_merkle_commit_devices(0, None, doc.ctypes.data, 8, False, None, 2, None, root.ctypes.data, None) == 1
+    assert lib.reef_merkle_commit_devices(0, None, doc.ctypes.data, 8, False, devs, 0, None, root.ctypes.data, None) == 1
+    assert lib.reef_merkle_commit_devices(9, None, doc.ctypes.data, 8, False, devs, 2, None, root.ctypes.data, None) == 1
 
 
 def test_unknown_curve_rejected():

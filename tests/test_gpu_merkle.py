@@ -127,3 +127,38 @@ def test_gpu_matches_committed_fixture(gpu_lib):
         p = M.standin_params(M.Q if case["scalar_field_of"] == "pallas" else M.P, 5, case["rf"], case["rp"])
         root, tree = merkle.commit(case["scalar_field_of"], case["doc"], p.t, p.rf, p.rp, p.rc, p.mds, p.tag_leaf, p.tag_node)
         assert hex(root) == case["root"] and [len(l) for l in tree] == case["level_sizes"] and hex(tree[0][0]) == case["first_leaf"]
+
+
+@pytest.mark.parametrize("members", [2, 3, 8])
+def test_tree_in_blocks_over_several_devices_is_the_same_tree(members, gpu_lib):
+    """reef_merkle_commit_devices (include/reef_msm.h 3d): the bottom level cut into power-of-two blocks, one per member (ordinals
+    repeat on a one-GPU box), the levels above hashed from the blocks' roots.  Node for node the oracle's tree for small ragged
+    documents (every way the last block can be short: one symbol, one node, an odd node count at every level), node for node
+    the one-device tree at 2^20 - 3 symbols; the root alone (no tree copied back); documents smaller than the member count."""
+    from reef_amd import merkle, msm
+    p = M.standin_params()
+    for n in (1, 2, 3, 5, 8, 9, 31, 33, 100, 257, 1001, 4097):
+        doc = [(37 * i + 11) % 131 for i in range(n)]
+        info = {}
+        root, tree = merkle.commit_arrays("pallas", np.asarray(doc, dtype=np.uint32), p.t, p.rf, p.rp, p.rc, p.mds, p.tag_leaf, p.tag_node,
+                                          devices=[0] * members, info=info)
+        eroot, etree = M.commit(doc, p)
+        from reef_amd.sumcheck import array_to_ints
+        assert [array_to_ints(lv) for lv in tree] == etree and root == eroot, n
+        m0, L = (n + 1) // 2, 0
+        while -(-m0 // (1 << L)) > members:
+            L += 1
+        assert info["blocks"] == -(-m0 // (1 << L))               # the smallest power-of-two block that leaves at most `members` blocks
+        if m0 >= members:
+            assert info["blocks"] > members // 2                  # ... which leaves fewer than half the members idle
+    n = (1 << 20) - 3
+    doc = np.random.default_rng(5).integers(0, 131, size=n, dtype=np.uint32)
+    root1, tree1 = merkle.commit_arrays("pallas", doc, p.t, p.rf, p.rp, p.rc, p.mds, p.tag_leaf, p.tag_node)
+    info = {}
+    root, tree = merkle.commit_arrays("pallas", doc, p.t, p.rf, p.rp, p.rc, p.mds, p.tag_leaf, p.tag_node, devices=[0] * members, info=info)
+    assert root == root1 and len(tree) == len(tree1) and all((a == b).all() for a, b in zip(tree, tree1))
+    assert info["blocks"] == {2: 2, 3: 2, 8: 8}[members]
+    root_only, none = merkle.commit_arrays("pallas", doc, p.t, p.rf, p.rp, p.rc, p.mds, p.tag_leaf, p.tag_node, want_tree=False, devices=[0] * members)
+    assert root_only == root1 and none == []
+    with pytest.raises(msm.ReefError):
+        merkle.commit_arrays("pallas", doc[:10], p.t, p.rf, p.rp, p.rc, p.mds, p.tag_leaf, p.tag_node, devices=[0, 99])

@@ -103,6 +103,7 @@ def test_bench_single_process_over_a_device_group(members, logn, exchange, gpu_l
         assert ss[k] > 0, k
     if logn >= 16:
         assert ss["hyrax_rows"]["check"] == "dlog-ok" and ss["hyrax_rows"]["rows"] == 4096
+        assert ss["merkle_commit"]["check"] == "same-root" and ss["merkle_commit"]["blocks"] == {2: 2, 3: 2}[members] and ss["merkle_commit"]["ms_per_commit"] > 0
     assert line["value"] > 0 and line["roofline"]["kernel_ms"] > 0 and cfg["host_scalars_ms_per_msm"] > 0
     refused = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT, env=dict(os.environ, WORLD_SIZE="2"))
     assert refused.returncode != 0 and "WITHOUT torch.distributed.run" in refused.stderr

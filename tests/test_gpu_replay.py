@@ -81,6 +81,18 @@ def test_replay_multi_device_leg_in_one_process(cfg, members, gpu_lib):
         replay.run("cfg1", nofold=False, devices=[0, 0])            # the leg replays the fold-free final SNARK
 
 
+def test_replay_multi_device_leg_builds_the_merkle_commitment_in_blocks(gpu_lib):
+    """cfg5 (--merkle, 2^27 symbols) with devices=4: the Poseidon tree in four blocks (reef_merkle_commit_devices), its root equal to
+    one device's (checked inside the replay); two arguments to place (merkle mode has no consistency IPA, commitment.rs:94-100)."""
+    from reef_amd import replay
+    line = replay.run("cfg5", nofold=True, devices=[0, 0, 0, 0])
+    dv = line["devices"]
+    assert [a["argument"] for a in dv["final_snark_placed"]] == ["ipa_pallas", "ipa_vesta"]
+    assert dv["commit_merkle_blocks"] == 4 and dv["commit_merkle_root_checked_against_one_device"] is True
+    assert dv["commit_merkle_devices_ms"] > 0 and dv["commit_merkle_one_device_ms"] > 0
+    assert dv["commit_rows_checked_against_one_device"] is False and dv["commit_hyrax_group_ms"] == 0
+
+
 def test_replay_executable(gpu_lib):
     """The same harness as a program (what profiles/*replay*.jsonl were recorded with): exit code 0 and one JSON line."""
     exe = os.path.join(ROOT, "reef_amd", "_lib", "reef_replay")

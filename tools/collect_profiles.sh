@@ -81,8 +81,13 @@ python $root/tools/pmc_traffic.py $out > $out/${R}_pmc_traffic.log 2>&1
 mkdir -p $root/profiles; cp $out/${R}_pmc_traffic.json $root/profiles/ 2>/dev/null      # bench.py reads roofline.traffic from profiles/ (refused when the kernel sources differ)
 python $root/bench.py --steps 20 --warmup 5 > $out/${R}_bench.json 2> $out/${R}_bench.err
 (cd /tmp && rm -rf /tmp/ks && rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/ks -- python $root/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-replay > $out/${R}_bench_under_rocprof.json 2>/dev/null; cp /tmp/ks/*/*kernel_stats.csv $out/${R}_kernel_stats.csv)
-(for m in 3 8; do $root/reef_amd/_lib/reef_replay cfg4 nofold devices=$m 2>/dev/null; done; $root/reef_amd/_lib/reef_replay cfg4b nofold 2>/dev/null) > $out/${R}_replay_devices.jsonl
+(for m in 3 8; do $root/reef_amd/_lib/reef_replay cfg4 nofold devices=$m 2>/dev/null; done; $root/reef_amd/_lib/reef_replay cfg4b nofold 2>/dev/null;
+ $root/reef_amd/_lib/reef_replay cfg5 nofold devices=8 2>/dev/null) > $out/${R}_replay_devices.jsonl
 python $root/tools/time_group.py > $out/${R}_group_timing.txt 2>&1
+python $root/tools/time_merkle.py 16 20 24 26 27 > $out/${R}_merkle_timing.txt 2>&1
+python $root/bench.py --gpus 2 --single-process --steps 3 --warmup 1 --msms-per-step 12 > $out/${R}_bench_single_process.jsonl 2>/dev/null
+python $root/bench.py --gpus 8 --single-process --steps 3 --warmup 1 --msms-per-step 12 >> $out/${R}_bench_single_process.jsonl 2>/dev/null
+python $root/bench.py --gpus 8 --single-process --group-exchange rccl --steps 3 --warmup 1 --msms-per-step 12 2>/dev/null | grep "^{" >> $out/${R}_bench_single_process.jsonl
 fi
 # the one-launch sum-check rounds under load, ten times the GPU suite's count, all three orderings of the hand-over (sumcheck_kernels.inc: SC_ORDER_*)
 (echo "# reef_amd/_lib/sc_stress <ell> <steps> load: one folding step repeated under k_accum0 + streaming load, every coefficient triple against the two-launch form; library sources $sha"

@@ -76,7 +76,14 @@ while time.time() < t_end:
     elif shape == 8:    # Poseidon Merkle tree (stand-in constants, any number of partial rounds)
         p = MO.standin_params(MO.Q if cid == 0 else MO.P, 5, int(rng.choice([2, 4, 8])), int(rng.integers(0, 60)))
         doc = [int(v) for v in rng.integers(0, 1 << 32, size=int(rng.integers(1, 120)), dtype=np.uint64)]
-        assert merkle.commit("pallas" if cid == 0 else "vesta", doc, p.t, p.rf, p.rp, p.rc, p.mds, p.tag_leaf, p.tag_node) == MO.commit(doc, p), ("merkle", cid, p.rf, p.rp, len(doc))
+        want = MO.commit(doc, p)
+        assert merkle.commit("pallas" if cid == 0 else "vesta", doc, p.t, p.rf, p.rp, p.rc, p.mds, p.tag_leaf, p.tag_node) == want, ("merkle", cid, p.rf, p.rp, len(doc))
+        if rng.integers(0, 2):    # the same tree in blocks over a group of members (reef_merkle_commit_devices)
+            from reef_amd.sumcheck import array_to_ints
+            members = int(rng.integers(1, 9))
+            root, tree = merkle.commit_arrays("pallas" if cid == 0 else "vesta", np.asarray(doc, dtype=np.uint32), p.t, p.rf, p.rp, p.rc, p.mds, p.tag_leaf, p.tag_node,
+                                              devices=[0] * members)
+            assert (root, [array_to_ints(lv) for lv in tree]) == want, ("merkle-blocks", cid, members, len(doc))
     elif shape == 9:    # commitments over folded generators, folds recorded not performed
         logn = int(rng.integers(1, 13))
         n = 1 << logn
