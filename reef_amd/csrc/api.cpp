@@ -433,7 +433,7 @@ reef_status reef_merkle_commit(int curve, const reef_poseidon_params *params, co
     return guarded([&] { return v->merkle_commit(params, doc, n, doc_loc, is_mont, tree_out, tree_loc, root_out, nullptr); });
 }
 
-// The same tree built by several devices of this process (include/reef_msm.h 5b).  The bottom level is cut into blocks of S = 2^L nodes, one
+// The same tree built by several devices of this process (include/reef_msm.h 3d).  The bottom level is cut into blocks of S = 2^L nodes, one
 // block per device; a block is a subtree of the whole tree, so the devices exchange nothing but their block's root (32 bytes each, through the
 // host), and the levels above L are hashed from those roots on devices[0].
 reef_status reef_merkle_commit_devices(int curve, const reef_poseidon_params *params, const uint32_t *doc, size_t n, bool is_mont, const int *devices,
