@@ -409,6 +409,29 @@ def test_two_level_sort_with_sparse_and_ragged_digits(name, n, kind, bound, gpu_
             assert msm.compress(name, ctx.msm(sc_dev, m)) == dlog(m), (groups, wbits, "prefix")
 
 
+@pytest.mark.parametrize("n,c", [(61439, 13), (61440, 15), (98304, 15), (180223, 15), (180224, 17)])
+def test_shipped_plan_either_side_of_the_window_thresholds_dlog_property(n, c, gpu_lib):
+    """choose_window (engine.inc; thresholds moved in round 5 on tools/sweep_window_mid.py's evidence): the plan a pre-shifted key gets
+    at the sizes where the window changes -- the longest one-level sort at c = 13 (61 439 x 20 entries), the two-level sort at c = 15
+    up to 180 223 points, c = 17 beyond -- uniform, witness-like and tiny scalars, a ragged prefix; expected: the discrete-log closed form."""
+    from reef_amd import msm
+    C = CURVES["pallas"]
+    k0, d = 0x7654321, 0x10F
+    bases = msm.gen_bases("pallas", k0, d, n, device=True)
+    idx = np.arange(n, dtype=object)
+    with msm.MsmContext("pallas", bases, n, bucket_groups=1) as ctx:
+        assert ctx.plan()["window_bits"] == c
+        for kind, bound in ((0, 0), (1, 0), (2, 5)):
+            sc_dev = msm.gen_scalars("pallas", 0xC0DE + kind, n, kind=kind, small_bound=bound, mont=True, device=True)
+            canon = msm.gen_scalars("pallas", 0xC0DE + kind, n, kind=kind, small_bound=bound, mont=False)
+            cols = [canon[:, j].astype(object) for j in range(4)]
+            for upto in (n, n - 4321):
+                acc = 0
+                for j in range(4):
+                    acc += (int(np.sum(cols[j][:upto])) * k0 + int(np.sum(cols[j][:upto] * idx[:upto])) * d) << (64 * j)
+                assert msm.compress("pallas", ctx.msm(sc_dev, upto)) == C.compress(C.mul(acc % C.order, C.gen)), (kind, upto)
+
+
 def test_linearity_and_clone_threads(gpu_lib, cref):
     """MSM(a) + MSM(b) == MSM(a+b); clones of one key used from several threads agree."""
     from reef_amd import msm
