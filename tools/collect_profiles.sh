@@ -86,7 +86,7 @@ python $root/bench.py --steps 20 --warmup 5 > $out/${R}_bench.json 2> $out/${R}_
 python $root/tools/time_group.py > $out/${R}_group_timing.txt 2>&1
 python $root/tools/time_merkle.py 16 20 24 26 27 > $out/${R}_merkle_timing.txt 2>&1
 python $root/tools/sweep_window_mid.py > $out/${R}_window_mid_sweep.txt 2>&1
-REEF_ROUND=$R python $root/tools/pmc_replay.py $out cfg3 > /dev/null 2>&1; REEF_ROUND=$R python $root/tools/pmc_replay.py $out cfg4 > /dev/null 2>&1
+REEF_ROUND=$R python $root/tools/pmc_replay.py $out cfg3 > /dev/null 2>&1; REEF_ROUND=$R python $root/tools/pmc_replay.py $out cfg4 > /dev/null 2>&1; REEF_ROUND=$R python $root/tools/pmc_replay.py $out cfg5 > /dev/null 2>&1
 python $root/bench.py --gpus 2 --single-process --steps 3 --warmup 1 --msms-per-step 12 > $out/${R}_bench_single_process.jsonl 2>/dev/null
 python $root/bench.py --gpus 8 --single-process --steps 3 --warmup 1 --msms-per-step 12 >> $out/${R}_bench_single_process.jsonl 2>/dev/null
 python $root/bench.py --gpus 8 --single-process --group-exchange rccl --steps 3 --warmup 1 --msms-per-step 12 2>/dev/null | grep "^{" >> $out/${R}_bench_single_process.jsonl
