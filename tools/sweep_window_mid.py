@@ -44,7 +44,7 @@ if __name__ == "__main__":
     sizes = [int(x) for x in sys.argv[1:]] or [32768, 40000, 49152, 57344, 65536, 81920, 98304, 131072, 163840, 196608, 262144, 393216, 524288]
     for n in sizes:
         row = []
-        for c in range(12, 19):
+        for c in range(int(os.environ.get("CMIN", "12")), int(os.environ.get("CMAX", "18")) + 1):
             try:
                 med, best, four = one(n, c)
             except msm.ReefError:

@@ -6,7 +6,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from reef_amd import msm
 h = np.ascontiguousarray(msm.gen_bases("pallas", 0xB11D, 1, 1)[0])
-for n in (1, 2, 16, 128, 512, 1024, 2048):
+for n in [int(a) for a in sys.argv[1:]] or (1, 2, 16, 128, 512, 1024, 2048):
     bases = msm.gen_bases("pallas", 5, 3, n, device=True)
     sc = msm.gen_scalars("pallas", 9, n)
     dsc = msm.DeviceBuffer.from_host(sc)
