@@ -2,7 +2,7 @@ root=$GRAFT_REPO_ROOT; out=$root/gpurun_out/long; mkdir -p $out
 sha=$(cd $root && python -c "from reef_amd import _ffi; print(_ffi.library_sources_sha16())")
 (echo "# reef_amd/_lib/sc_stress <ell> <steps> load, REEF_SC_FENCE=0 (the shipped hand-over), ten times the steps of r05_sc_stress.txt; library sources $sha"
  run() { env REEF_SC_FENCE=0 $2 $root/reef_amd/_lib/sc_stress $1 $3 load; }
- n=200000
+ n=${STRESS_STEPS:-200000}
  run 12 "REEF_SC_BLOCKS=2 REEF_SC_ITEMS=1 REEF_SC_SPLIT_MAX=0" $n
  run 18 "REEF_SC_BLOCKS=3 REEF_SC_ITEMS=1 REEF_SC_SPLIT_MAX=0" $n
  run 16 "REEF_SC_BLOCKS=16 REEF_SC_ITEMS=1 REEF_SC_SPLIT_MAX=0" $n
