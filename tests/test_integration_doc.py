@@ -82,3 +82,30 @@ def test_repr_c_structs_list_the_header_fields_in_order():
         body = re.search(r"#\[repr\(C\)\]\s*(?:pub\s+)?struct\s+" + rust + r"\s*\{(.*?)\}", doc, flags=re.S).group(1)
         names = [f.split(":")[0].strip() for f in _split_top(_strip_comments(body))]
         assert names == _c_struct_fields(c), f"{rust}: {names} against {c}: {_c_struct_fields(c)}"
+
+
+def test_the_ctypes_binding_matches_the_header():
+    """reef_amd/_ffi.py is how every GPU test, the soak and bench.py reach the library: an argument of the wrong width there would be a bug
+    in the checker, not in the product.  Every function the binding declares is compared with the header's prototype."""
+    import ctypes
+
+    from reef_amd import _ffi
+    lib = _ffi.load()                                    # loads without a GPU (tests/test_abi.py)
+    protos = _header_prototypes()
+
+    def kind(t):
+        if t is None:
+            return "void"
+        if t in (ctypes.c_void_p, ctypes.c_char_p) or hasattr(t, "contents"):
+            return "ptr"
+        return {ctypes.c_int: "i32", ctypes.c_uint32: "u32", ctypes.c_uint64: "u64", ctypes.c_bool: "bool"}[t]   # c_size_t IS c_uint64 here
+    bound = 0
+    for name, (ret_, args_) in protos.items():
+        want = (ret_.replace("usize", "u64"), [a.replace("usize", "u64") for a in args_])
+        fn = getattr(lib, name)
+        if fn.argtypes is None:
+            continue                                     # declared in the header, not used from Python
+        got = (kind(fn.restype), [kind(t) for t in fn.argtypes])
+        assert got == want, f"{name}: _ffi.py declares {got}, the header {want}"
+        bound += 1
+    assert bound >= 60
