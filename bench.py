@@ -728,6 +728,134 @@ def main():
     last = (a.steps * MPS - 1) % nctx
     final_parts = parts[last].cpu().numpy().copy()
     final_result = results[last].cpu().numpy().copy()
+    single = None
+    host_ms = None
+    host_pageable = None
+
+    # ---- N > 1: the timed region's own result is checked BEFORE any side leg runs, and the side legs run under a deadline ----
+    # Everything from here to the end of the run has never met more than one physical GPU (RCCL on > 1 rank, peer copies between
+    # devices, the child process over all devices): if one of its collectives hangs, the measured line must not hang with it.  So
+    # (1) the weak region's combined point is compared with its discrete logarithm first, on every rank (weak_check below: the same
+    # collectives the check used after the legs until round 5), and (2) a watchdog thread on every rank waits REEF_BENCH_SIDE_TIMEOUT
+    # seconds (default 480) for the rest of the run: when they pass, rank 0 prints the line it has -- `value` of the completed timed
+    # region, the weak check's verdict, `strong_scaling` = the error -- and every rank leaves through os._exit (a rank stuck in a
+    # collective cannot be unwound).  A run that finishes in time never notices any of this.
+    import threading
+    weak = None                      # (ok, partials_differ, discrete logarithm of rank 0's MSM) once weak_check has run
+    line_state = {"lock": threading.Lock(), "done": False, "build": None}
+    run_finished = threading.Event()
+
+    def emit(line):
+        with line_state["lock"]:
+            if line_state["done"]:
+                return False
+            line_state["done"] = True
+        os.write(json_fd, (json.dumps(line) + "\n").encode())
+        return True
+
+    def weak_check():
+        canon_ = msm.gen_scalars(a.curve, seed, n * B, kind=kind, mont=False)
+        my_dlog_ = dlog_of_msm(a.curve, canon_[:n], k0, d, owner * n)
+        cdev_ = dev if a.backend == "nccl" else "cpu"
+        got_total = msm.compress(a.curve, final_result.view(np.uint64))
+        got_part = msm.compress(a.curve, final_parts.view(np.uint64))
+        words = torch.tensor([(my_dlog_ >> (32 * j)) & 0xFFFFFFFF for j in range(8)], dtype=torch.int64, device=cdev_)
+        allw = [torch.zeros_like(words) for _ in range(a.gpus)]
+        dist.all_gather(allw, words)
+        dlogs = [sum(int(v) << (32 * j) for j, v in enumerate(w.tolist())) for w in allw]
+        if by_windows:                    # every rank holds the same MSM; only the combined point is one
+            total_dlog, ok_ = my_dlog_, True
+        else:                             # points: the rank's partial is its own slice's MSM, the total is the sum of the slices
+            ok_ = got_part == point_of_dlog(a.curve, my_dlog_)
+            total_dlog = sum(dlogs)
+        ok_ = ok_ and got_total == point_of_dlog(a.curve, total_dlog)     # EVERY rank checks the combined point against the expected total
+        differ_ = (got_part != got_total) if a.gpus > 1 else None
+        flag = torch.tensor([1 if ok_ else 0, 1 if (differ_ or a.gpus == 1) else 0], device=cdev_)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        return bool(flag[0].item()), (bool(flag[1].item()) if a.gpus > 1 else None), dlogs[0]
+
+    def build_line(check, partials_differ, strong):
+        # HBM traffic of the dominant kernel: PMC counters need their own rocprofv3 passes (never
+        # combined with timing), so the value is read from the committed profile of this command
+        # a profile is taken only if it was collected on the kernels this run executes (sources fingerprint) and on this plan; a stale
+        # one is refused rather than quoted (no fall-back to an older round's file)
+        traffic, traffic_src = None, None
+        from reef_amd import _ffi as _f
+        prof_name = "r05_pmc_traffic.json"
+        try:
+            prof = json.load(open(os.path.join(ROOT, "profiles", prof_name)))
+            pc = prof["config"]
+            same_plan = (pc["curve"], pc["logn"], pc["window_bits"], pc["bucket_groups"]) == (a.curve, a.logn, plan["window_bits"], plan["bucket_groups"])
+            if prof.get("kernel_sources_sha16") != _f.kernel_sources_sha16():
+                traffic_src = f"REFUSED: profiles/{prof_name} was collected on other kernel sources ({prof.get('kernel_sources_sha16')} != {_f.kernel_sources_sha16()}); re-run tools/pmc_traffic.py"
+            elif not same_plan:
+                traffic_src = f"REFUSED: profiles/{prof_name} describes another plan ({pc})"
+            else:
+                accum = [v for k, v in prof["kernels"].items() if k.startswith(f"k_accum0<{msm.curve_id(a.curve)}")]
+                traffic = max(v["hbm_bytes_per_launch"] for v in accum)
+                traffic_src = f"profiles/{prof_name} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes on kernel sources {prof['kernel_sources_sha16']})"
+        except (OSError, KeyError, ValueError) as e:
+            traffic_src = f"no usable profiles/{prof_name}: {e}"
+        pairs = n * B * MPS * (1 if by_windows else a.gpus) * a.steps
+        value = pairs / elapsed
+        achieved = BYTES_PER_PAIR * n * B / (acc_ms * 1e-3) / 1e9 if acc_ms > 0 else None
+        eff_windows = min(plan["windows"], -(-255 // plan["window_bits"]))   # windows that hold scalar bits (scalars < 2^255)
+        out = {
+            "metric": "msm_scalar_point_pairs_per_sec", "value": value, "unit": "pairs/s", "n_gpus": a.gpus,
+            "steps": a.steps, "warmup": a.warmup, "ms_per_step": elapsed / a.steps * 1e3, "higher_is_better": True,
+            "scaling": "strong" if by_windows else "weak", "vs_baseline": None, "dtype": "u32", "data": "synthetic",
+            "config": {"workload": f"2^{a.logn}-point {a.curve.capitalize()} MSM per GPU, {a.scalars} 255-bit scalars, "
+                                   f"resident key, device-resident scalars (BASELINE.json configs[1]); a step = a batch of {MPS * B} such MSMs",
+                       "scalars": "device-resident (generated on the GPU before the timed region; no PCIe traffic inside it)",
+                       "host_scalars_ms_per_msm": host_ms,
+                       "host_scalars_pageable_ms_per_msm": host_pageable,
+                       "host_scalars_note": "same MSMs with the scalars in host memory and the result returned to the host, caller threads each on its own clone of "
+                                            "the resident key; PCIe-inclusive, measured after the timed region, never `value`.  host_scalars_ms_per_msm: PINNED memory, six "
+                                            "callers; host_scalars_pageable_ms_per_msm: ordinary pageable memory (what a Rust Vec is), one caller and six",
+                       "points_per_gpu": n, "total_points": n * (1 if by_windows else a.gpus), "window_bits": plan["window_bits"],
+                       "windows": plan["windows"], "bucket_groups": plan["bucket_groups"], "tables": plan["tables"],
+                       "streams": nctx, "msms_per_step": MPS * B, "ms_per_msm": elapsed / (a.steps * MPS * B) * 1e3, "sharding": ("windows (w = rank mod N)" if by_windows else "points") if a.gpus > 1 else "none",
+                       "exchange": ("none" if a.gpus == 1 else "rccl all_gather of 96 B partials + on-device add" if a.backend == "nccl"
+                                    else "HOST-STAGED gloo all_gather of 96 B partials (debug fallback, not RCCL) + on-device add"),
+                       "check": check, "partials_differ_from_total": partials_differ, "msm_ms_stream": tot_ms,
+                       "strong_scaling": strong,
+                       "rccl": ({"ranks_seen": dist.get_world_size(), "backend": a.backend, "stream_ordered": stream_ordered} if multi else None),
+                       "streams_of_the_contexts": (len({c_.stream for c_ in ctxs}) if multi else None)},
+            "roofline": {"bound": "hbm", "kernel": "k_accum0 (bucket accumulation)", "achieved": achieved, "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": traffic,
+                         "traffic_source": traffic_src,
+                         "kernel_ms": acc_ms, "algorithmic_bytes_per_launch": BYTES_PER_PAIR * n * B,
+                         "note": f"kernel_ms = average launch duration with {nctx} MSMs in flight (launches stretch each other); single_stream = one MSM in flight",
+                         "single_stream": ({"kernel_ms": single["kernel_ms"], "msm_ms": single["msm_ms"],
+                                            "achieved": BYTES_PER_PAIR * n / (single["kernel_ms"] * 1e-3) / 1e9,
+                                            "frac": BYTES_PER_PAIR * n / (single["kernel_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS}
+                                           if single and single["kernel_ms"] > 0 else None),
+                         # the kernel is bound by integer issue, not HBM (DESIGN.md 5): whole-job field products per second
+                         # (10 per bucket addition, one addition per non-zero digit ~ windows-1 per pair) against the
+                         # measured chip-wide rate of the Montgomery product (reef_bench_fmul)
+                         "issue": {"field_products_per_s": value / a.gpus * eff_windows * 10, "peak": FMUL_PEAK,
+                                   "frac": value / a.gpus * eff_windows * 10 / FMUL_PEAK, "unit": "products/s"}},
+        }
+        return out
+    line_state["build"] = build_line
+
+    if multi and not a.no_check:
+        weak = weak_check()
+    if multi and a.gpus > 1:
+        side_deadline = float(os.environ.get("REEF_BENCH_SIDE_TIMEOUT", "480"))   # below the 600 s after which torch aborts a rank waiting in an RCCL collective
+
+        def watchdog():
+            if run_finished.wait(side_deadline):
+                return
+            why = (f"the legs after the timed region did not finish within {side_deadline:.0f} s (REEF_BENCH_SIDE_TIMEOUT): one of their collectives or the "
+                   "child process hangs; the timed region itself had completed on every rank (closing barrier and max-over-ranks all_reduce returned)")
+            print(f"[bench] rank {rank}: {why}", file=sys.stderr)
+            if rank == 0 and line_state["build"] is not None:
+                verdict = "skipped" if weak is None else ("dlog-ok (timed region; the strong-scaling legs never finished)" if weak[0] else "MISMATCH")
+                emit(line_state["build"](verdict, weak[1] if weak else None, {"error": why}))
+            sys.stderr.flush()
+            os._exit(2 if (weak is not None and not weak[0]) else 0)
+        threading.Thread(target=watchdog, daemon=True).start()
 
     # ---- N > 1, after the timed region (never `value`): the two STRONG splits of ONE 2^logn-point MSM on the same ranks ----
     # (a) by Pippenger window, the split north_star names: every rank holds all points and scalars and accumulates the
@@ -868,7 +996,7 @@ def main():
                                                                           "LOCAL_WORLD_SIZE", "ROLE_WORLD_SIZE", "TORCHELASTIC_RUN_ID") and not k.startswith("TORCHELASTIC")}
                     for field, ex in (("single_process", "peer"), ("single_process_rccl", "rccl")):
                         child = subprocess.run([sys.executable, os.path.abspath(__file__), "--gpus", str(a.gpus), "--single-process", "--group-exchange", ex, "--logn", str(a.logn),
-                                                "--steps", "2", "--warmup", "1", "--msms-per-step", "12", "--curve", a.curve], capture_output=True, text=True, timeout=240, env=env)
+                                                "--steps", "2", "--warmup", "1", "--msms-per-step", "12", "--curve", a.curve], capture_output=True, text=True, timeout=150, env=env)
                         lines = [ln for ln in child.stdout.splitlines() if ln.startswith("{")]
                         if child.returncode == 0 and lines:
                             cl = json.loads(lines[-1])
@@ -891,9 +1019,6 @@ def main():
     # ---- after the timed region (none of this is `value`) ------------------------------------------------
     # (1) the accumulation kernel with ONE MSM in flight: with several MSMs sharing the chip a launch is stretched by
     #     its neighbours, so the per-launch duration above understates the kernel
-    single = None
-    host_ms = None
-    host_pageable = None
     if not multi:
         reps = max(3, min(10, a.steps * MPS))
         for _ in range(reps):
@@ -943,105 +1068,31 @@ def main():
     if not a.no_check:
         # size-independent parity check of the last result (outside the timed region): bases are an arithmetic
         # progression, so every MSM over them has a known discrete log
-        canon = msm.gen_scalars(a.curve, seed, n * B, kind=kind, mont=False)
-        my_dlog = dlog_of_msm(a.curve, canon[:n], k0, d, owner * n)
         if not multi:
+            canon = msm.gen_scalars(a.curve, seed, n * B, kind=kind, mont=False)
+            my_dlog = dlog_of_msm(a.curve, canon[:n], k0, d, owner * n)
             ok = msm.compress(a.curve, final_result[:96].view(np.uint64)) == point_of_dlog(a.curve, my_dlog)
             for r in range(1, B):             # every MSM of the batch
                 ok = ok and msm.compress(a.curve, final_result[96 * r:96 * (r + 1)].view(np.uint64)) == point_of_dlog(
                     a.curve, dlog_of_msm(a.curve, canon[r * n:(r + 1) * n], k0, d, 0))
         else:
-            cdev = dev if a.backend == "nccl" else "cpu"
-            got_total = msm.compress(a.curve, final_result.view(np.uint64))
-            got_part = msm.compress(a.curve, final_parts.view(np.uint64))
-            if by_windows:                    # every rank holds the same MSM; only the combined point is one
-                total_dlog = my_dlog
-                ok = True
-            else:                             # points: the rank's partial is its own slice's MSM, the total is the sum of the slices
-                ok = got_part == point_of_dlog(a.curve, my_dlog)
-                words = torch.tensor([(my_dlog >> (32 * j)) & 0xFFFFFFFF for j in range(8)], dtype=torch.int64, device=cdev)
-                allw = [torch.zeros_like(words) for _ in range(a.gpus)]
-                dist.all_gather(allw, words)
-                total_dlog = sum(sum(int(v) << (32 * j) for j, v in enumerate(w.tolist())) for w in allw)
-            ok = ok and got_total == point_of_dlog(a.curve, total_dlog)     # EVERY rank checks the combined point against the expected total
-            if strong_results:                # both strong splits computed rank 0's MSM: its discrete log is the first gathered one
-                dlog0 = sum(int(v) << (32 * j) for j, v in enumerate(allw[0].tolist()))
+            # the timed region's own points were checked before the side legs (weak_check above); what is left are the strong legs' results:
+            # both splits computed rank 0's MSM, whose discrete logarithm is the first gathered one
+            ok, partials_differ, dlog0 = weak
+            if strong_results:
                 want0 = point_of_dlog(a.curve, dlog0)
                 for name_, res_ in strong_results.items():
                     if isinstance(res_, bool):
                         ok = ok and res_
                     else:
                         ok = ok and msm.compress(a.curve, res_.view(np.uint64)) == want0
-            partials_differ = (got_part != got_total) if a.gpus > 1 else None
-            flag = torch.tensor([1 if ok else 0, 1 if (partials_differ or a.gpus == 1) else 0], device=cdev)
+            flag = torch.tensor([1 if ok else 0], device=dev if a.backend == "nccl" else "cpu")
             dist.all_reduce(flag, op=dist.ReduceOp.MIN)
             ok = bool(flag[0].item())
-            if a.gpus > 1:
-                partials_differ = bool(flag[1].item())
         check = "dlog-ok" if ok else "MISMATCH"
 
     if rank == 0:
-        # HBM traffic of the dominant kernel: PMC counters need their own rocprofv3 passes (never
-        # combined with timing), so the value is read from the committed profile of this command
-        # a profile is taken only if it was collected on the kernels this run executes (sources fingerprint) and on this plan; a stale
-        # one is refused rather than quoted (no fall-back to an older round's file)
-        traffic, traffic_src = None, None
-        from reef_amd import _ffi as _f
-        prof_name = "r05_pmc_traffic.json"
-        try:
-            prof = json.load(open(os.path.join(ROOT, "profiles", prof_name)))
-            pc = prof["config"]
-            same_plan = (pc["curve"], pc["logn"], pc["window_bits"], pc["bucket_groups"]) == (a.curve, a.logn, plan["window_bits"], plan["bucket_groups"])
-            if prof.get("kernel_sources_sha16") != _f.kernel_sources_sha16():
-                traffic_src = f"REFUSED: profiles/{prof_name} was collected on other kernel sources ({prof.get('kernel_sources_sha16')} != {_f.kernel_sources_sha16()}); re-run tools/pmc_traffic.py"
-            elif not same_plan:
-                traffic_src = f"REFUSED: profiles/{prof_name} describes another plan ({pc})"
-            else:
-                accum = [v for k, v in prof["kernels"].items() if k.startswith(f"k_accum0<{msm.curve_id(a.curve)}")]
-                traffic = max(v["hbm_bytes_per_launch"] for v in accum)
-                traffic_src = f"profiles/{prof_name} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes on kernel sources {prof['kernel_sources_sha16']})"
-        except (OSError, KeyError, ValueError) as e:
-            traffic_src = f"no usable profiles/{prof_name}: {e}"
-        pairs = n * B * MPS * (1 if by_windows else a.gpus) * a.steps
-        value = pairs / elapsed
-        achieved = BYTES_PER_PAIR * n * B / (acc_ms * 1e-3) / 1e9 if acc_ms > 0 else None
-        eff_windows = min(plan["windows"], -(-255 // plan["window_bits"]))   # windows that hold scalar bits (scalars < 2^255)
-        out = {
-            "metric": "msm_scalar_point_pairs_per_sec", "value": value, "unit": "pairs/s", "n_gpus": a.gpus,
-            "steps": a.steps, "warmup": a.warmup, "ms_per_step": elapsed / a.steps * 1e3, "higher_is_better": True,
-            "scaling": "strong" if by_windows else "weak", "vs_baseline": None, "dtype": "u32", "data": "synthetic",
-            "config": {"workload": f"2^{a.logn}-point {a.curve.capitalize()} MSM per GPU, {a.scalars} 255-bit scalars, "
-                                   f"resident key, device-resident scalars (BASELINE.json configs[1]); a step = a batch of {MPS * B} such MSMs",
-                       "scalars": "device-resident (generated on the GPU before the timed region; no PCIe traffic inside it)",
-                       "host_scalars_ms_per_msm": host_ms,
-                       "host_scalars_pageable_ms_per_msm": host_pageable,
-                       "host_scalars_note": "same MSMs with the scalars in host memory and the result returned to the host, caller threads each on its own clone of "
-                                            "the resident key; PCIe-inclusive, measured after the timed region, never `value`.  host_scalars_ms_per_msm: PINNED memory, six "
-                                            "callers; host_scalars_pageable_ms_per_msm: ordinary pageable memory (what a Rust Vec is), one caller and six",
-                       "points_per_gpu": n, "total_points": n * (1 if by_windows else a.gpus), "window_bits": plan["window_bits"],
-                       "windows": plan["windows"], "bucket_groups": plan["bucket_groups"], "tables": plan["tables"],
-                       "streams": nctx, "msms_per_step": MPS * B, "ms_per_msm": elapsed / (a.steps * MPS * B) * 1e3, "sharding": ("windows (w = rank mod N)" if by_windows else "points") if a.gpus > 1 else "none",
-                       "exchange": ("none" if a.gpus == 1 else "rccl all_gather of 96 B partials + on-device add" if a.backend == "nccl"
-                                    else "HOST-STAGED gloo all_gather of 96 B partials (debug fallback, not RCCL) + on-device add"),
-                       "check": check, "partials_differ_from_total": partials_differ, "msm_ms_stream": tot_ms,
-                       "strong_scaling": strong,
-                       "rccl": ({"ranks_seen": dist.get_world_size(), "backend": a.backend, "stream_ordered": stream_ordered} if multi else None),
-                       "streams_of_the_contexts": (len({c_.stream for c_ in ctxs}) if multi else None)},
-            "roofline": {"bound": "hbm", "kernel": "k_accum0 (bucket accumulation)", "achieved": achieved, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": traffic,
-                         "traffic_source": traffic_src,
-                         "kernel_ms": acc_ms, "algorithmic_bytes_per_launch": BYTES_PER_PAIR * n * B,
-                         "note": f"kernel_ms = average launch duration with {nctx} MSMs in flight (launches stretch each other); single_stream = one MSM in flight",
-                         "single_stream": ({"kernel_ms": single["kernel_ms"], "msm_ms": single["msm_ms"],
-                                            "achieved": BYTES_PER_PAIR * n / (single["kernel_ms"] * 1e-3) / 1e9,
-                                            "frac": BYTES_PER_PAIR * n / (single["kernel_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS}
-                                           if single and single["kernel_ms"] > 0 else None),
-                         # the kernel is bound by integer issue, not HBM (DESIGN.md 5): whole-job field products per second
-                         # (10 per bucket addition, one addition per non-zero digit ~ windows-1 per pair) against the
-                         # measured chip-wide rate of the Montgomery product (reef_bench_fmul)
-                         "issue": {"field_products_per_s": value / a.gpus * eff_windows * 10, "peak": FMUL_PEAK,
-                                   "frac": value / a.gpus * eff_windows * 10 / FMUL_PEAK, "unit": "products/s"}},
-        }
+        out = build_line(check, partials_differ, strong)
         side_legs = a.gpus == 1 and not multi and not a.no_replay
         if side_legs:                      # GPU side legs first: they are host-latency sensitive (see replay_leg)
             _diag("before closing the contexts")
@@ -1069,9 +1120,11 @@ def main():
                         replay_cpu_leg(out["config"]["replay_" + cfg_], cfg_, cpu_threads=out["cpu_baseline"].get("cores"))
                     except Exception as e:
                         out["config"]["replay_" + cfg_]["cpu_error"] = str(e)
-        os.write(json_fd, (json.dumps(out) + "\n").encode())
+        emit(out)
     if multi:
         dist.barrier()
+    run_finished.set()
+    if multi:
         dist.destroy_process_group()
     if check == "MISMATCH":
         sys.exit(2)

@@ -70,6 +70,25 @@ def test_bench_with_two_ranks(sharding, logn, gpu_lib):
     assert line["value"] > 0 and line["roofline"]["kernel_ms"] > 0
 
 
+def test_side_legs_under_a_deadline(gpu_lib):
+    """The legs after the timed region (strong splits, whole units, the single-process child) have never met two physical GPUs: if one of
+    their collectives hangs, the line of the completed timed region must still be printed.  With a one-second deadline the watchdog fires in
+    the middle of the strong legs: rank 0 prints the line it has -- the weak region's value, already checked by discrete logarithm -- and
+    every rank leaves with exit code 0."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--logn", "16", "--steps", "4",
+           "--warmup", "1", "--no-cpu-baseline"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", REEF_BENCH_SIDE_TIMEOUT="1"), cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [ln for ln in out.stdout.strip().splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    line = json.loads(lines[0])
+    cfg = line["config"]
+    assert cfg["check"].startswith("dlog-ok (timed region") and "REEF_BENCH_SIDE_TIMEOUT" in cfg["strong_scaling"]["error"]
+    assert cfg["partials_differ_from_total"] is True and line["value"] > 0 and line["n_gpus"] == 2 and line["scaling"] == "weak"
+    assert "did not finish within 1 s" in out.stderr
+
+
 def test_world_size_must_match_gpus(gpu_lib):
     """--gpus N under a launcher with another world size is refused instead of quietly measuring something else."""
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
