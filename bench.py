@@ -37,6 +37,10 @@ BYTES_PER_PAIR = 96            # 32 B scalar + 64 B affine base,
 FMUL_PEAK = 1.57e11            # Montgomery products/s chip-wide, measured (reef_bench_fmul, profiles/README.md)
 
 
+import threading as _threading
+WATCHDOG_FIRED = _threading.Event()     # set by the N > 1 watchdog of the side legs (main)
+
+
 def parse():
     p = argparse.ArgumentParser()
     p.add_argument("--gpus", type=int, default=1)
@@ -849,11 +853,13 @@ def main():
                 return
             why = (f"the legs after the timed region did not finish within {side_deadline:.0f} s (REEF_BENCH_SIDE_TIMEOUT): one of their collectives or the "
                    "child process hangs; the timed region itself had completed on every rank (closing barrier and max-over-ranks all_reduce returned)")
+            WATCHDOG_FIRED.set()       # from here on an exception in the main thread (a peer that has left) waits for this thread instead of ending the process
             print(f"[bench] rank {rank}: {why}", file=sys.stderr)
             if rank == 0 and line_state["build"] is not None:
                 verdict = "skipped" if weak is None else ("dlog-ok (timed region; the strong-scaling legs never finished)" if weak[0] else "MISMATCH")
                 emit(line_state["build"](verdict, weak[1] if weak else None, {"error": why}))
             sys.stderr.flush()
+            time.sleep(1.0)            # the ranks' deadlines lie milliseconds apart: nobody leaves before every rank's watchdog has fired
             os._exit(2 if (weak is not None and not weak[0]) else 0)
         threading.Thread(target=watchdog, daemon=True).start()
 
@@ -1131,4 +1137,9 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    try:
+        main()
+    except BaseException:
+        if WATCHDOG_FIRED.is_set():    # the side legs' deadline has passed and this rank's collective broke because a peer left: the watchdog ends the process
+            time.sleep(60)
+        raise
