@@ -588,6 +588,9 @@ def single_process_main(a):
 
 def main():
     a = parse()
+    # RCCL between processes (and CUDA-tensor sharing) needs dmabuf IPC on this pool's host driver; the boxes export it already -- kept here so that a
+    # launcher with a scrubbed environment does not end in `hipIpcGetMemHandle: invalid argument`.  Before anything initialises HIP; children inherit it.
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     if a.single_process:
         if int(os.environ.get("WORLD_SIZE", "1")) > 1:
             raise SystemExit("bench.py --single-process runs WITHOUT torch.distributed.run: one process drives all the devices")
