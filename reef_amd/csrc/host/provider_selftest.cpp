@@ -3,9 +3,11 @@
 // recomputes every entry with the oracle from the same seeds and compares bit for bit.
 // Build: g++ -O2 -std=c++17 provider_selftest.cpp -I../../../include -L../../_lib -lreef_msm -o provider_selftest
 #include <cstdio>
+#include <cstring>
 #include <string>
 
 #include "reef_provider.hpp"
+#include "replay_standins.h"   // stand-in hash-to-curve / Poseidon constants (generated from the oracle's; NOT pasta_curves' / neptune's)
 
 using namespace reef_provider;
 
@@ -104,6 +106,45 @@ int main() {
             else sc.fold(i, rs[i - 1]);
         }
         out += "], \"sumcheck_final\": \"" + fhex(sc.final_value()) + "\", ";
+        // ---- CommitmentGens::new(label, n) / new_with_blinding_gen: the key derived from a label on the GPU (row N1), commitments over it
+        {
+            reef_keygen_params kp;
+            kp.a = STANDIN_KEYGEN_0[0]; kp.b = STANDIN_KEYGEN_0[1]; kp.z = STANDIN_KEYGEN_0[2];
+            memcpy(kp.iso, STANDIN_KEYGEN_0 + 3, 13 * sizeof(reef_fe));
+            kp.dst = (const uint8_t *)STANDIN_KEYGEN_DST_0; kp.dst_len = (uint32_t)strlen(STANDIN_KEYGEN_DST_0); kp.little_endian = 0;
+            const size_t ln = 300;
+            CommitmentGens<REEF_PALLAS> lk("reef ck", ln, kp, &h);
+            std::vector<reef_fe> lv(ln);
+            check(reef_gen_scalars(REEF_PALLAS, 99, 1, 0, ln, true, lv.data(), REEF_HOST), "gen_scalars");
+            out += "\"label_commit\": \"" + chex<REEF_PALLAS>(lk.commit(lv.data(), ln)) + "\", ";
+            out += "\"label_commit_blind\": \"" + chex<REEF_PALLAS>(lk.commit(lv.data(), ln, blind.data())) + "\", ";
+            const auto lg = CommitmentGens<REEF_PALLAS>::from_label("reef ck", 3, kp);
+            out += "\"label_gens\": \"" + hex((const uint8_t *)lg.data(), 3 * sizeof(reef_affine)) + "\", ";
+        }
+        // ---- MerkleCommitment::new(&doc, &pc), path_wits (row N4; the reference's own document of make_mt, merkle_tree.rs:214, and a longer one in blocks)
+        {
+            reef_poseidon_params pp;
+            pp.width = 5; pp.full_rounds = STANDIN_POSEIDON_RF; pp.partial_rounds = STANDIN_POSEIDON_RP; pp.reserved = 0;
+            pp.round_constants = STANDIN_POSEIDON_RC; pp.mds = STANDIN_POSEIDON_MDS;
+            pp.tag_leaf = STANDIN_POSEIDON_TAGS[0]; pp.tag_node = STANDIN_POSEIDON_TAGS[1];
+            auto path_json = [&](const std::vector<MerkleWit> &w) {
+                std::string j = "[";
+                for (size_t i = 0; i < w.size(); ++i)
+                    j += std::string(i ? ", " : "") + "[" + (w[i].l_or_r ? "true" : "false") + ", " + (w[i].has_idx ? std::to_string(w[i].opposite_idx) : "null") +
+                         ", \"" + fhex(w[i].opposite) + "\"]";
+                return j + "]";
+            };
+            MerkleCommitment<REEF_PALLAS> mt({2, 3, 4, 5, 6, 7, 8}, pp);
+            out += "\"merkle_root\": \"" + fhex(mt.commitment) + "\", \"merkle_levels\": " + std::to_string(mt.tree.size()) + ", ";
+            out += "\"merkle_path6\": " + path_json(mt.path_wits(6)) + ", \"merkle_path3\": " + path_json(mt.make_wits({0, 3})[1]) + ", ";
+            std::vector<uint32_t> longdoc(1001);
+            for (size_t i = 0; i < longdoc.size(); ++i) longdoc[i] = (uint32_t)((31 * i + 7) % 131);
+            MerkleCommitment<REEF_PALLAS> mb(longdoc, pp, false, {0, 0, 0});
+            out += "\"merkle_blocks_root\": \"" + fhex(mb.commitment) + "\", \"merkle_blocks_path500\": " + path_json(mb.path_wits(500)) + ", ";
+            bool oob = false;
+            try { mt.path_wits(7); } catch (const std::out_of_range &) { oob = true; }
+            out += std::string("\"merkle_oob_throws\": ") + (oob ? "true" : "false") + ", ";
+        }
         // ---- error behaviour: a failure is an exception carrying the library's message
         bool threw = false;
         try { ck.commit(v.data(), n + 1); } catch (const Error &e) { threw = e.status != REEF_OK; }

@@ -12,6 +12,8 @@
 //       ::commit / ::commit_rows / ::commit_symbols   CE::commit split by Pippenger window over the devices, HyraxPC::commit rows dealt out whole
 //   SumCheck                                      gen_eq_table / linear_mle_product      src/backend/r1cs_helper.rs:441-544, driven as in r1cs.rs:2318-2385
 //   compress()                                    Commitment::compress                   src/backend/commitment.rs:195,351,365
+//   CommitmentGens<CURVE>(label, n, params [, h]) CommitmentGens::new(label, n) / new_with_blinding_gen      src/backend/framework.rs:297-303, commitment.rs:146-149,176-180
+//   MerkleCommitment<CURVE>(doc, pc)              MerkleCommitment::new(&doc, &pc), path_wits, make_wits     src/backend/merkle_tree.rs:25-190
 //
 // Error behaviour: Reef treats every failure as a panic (framework.rs:683,702); here every failed
 // call throws reef_provider::Error carrying reef_last_error().
@@ -53,6 +55,30 @@ template <int CURVE> class CommitmentGens {
         o.device = -1;
         check(reef_msm_ctx_create(&ctx_, CURVE, gens, n, gens_loc, &o), "reef_msm_ctx_create");
         if (h) h_ = *h;
+    }
+    // CommitmentGens::new(label, n) [R] / the fork's new_with_blinding_gen(label, n, &h): the n generators are derived from the label on the GPU
+    // (row N1: reef_derive_generators) straight into the resident key -- they never visit the host.  pasta_curves' hash-to-curve constants are
+    // the caller's (`kp`: canonical integers of the base field unless kp_is_mont).
+    CommitmentGens(const std::string &label, size_t n, const reef_keygen_params &kp, const reef_affine *h = nullptr, bool kp_is_mont = false, bool preshift = true)
+        : n_(n), has_h_(h != nullptr) {
+        reef_affine *dev = (reef_affine *)reef_device_alloc(n * sizeof(reef_affine));
+        if (!dev) throw Error(REEF_ERR_OOM, "reef_device_alloc");
+        reef_status st = reef_derive_generators(CURVE, (const uint8_t *)label.data(), label.size(), n, &kp, kp_is_mont, dev, REEF_DEVICE);
+        if (st == REEF_OK) {
+            reef_msm_opts o = {};
+            o.bucket_groups = preshift ? 1 : 0;
+            o.device = -1;
+            st = reef_msm_ctx_create(&ctx_, CURVE, dev, n, REEF_DEVICE, &o);
+        }
+        reef_device_free(dev);
+        check(st, "CommitmentGens::new(label, n)");
+        if (h) h_ = *h;
+    }
+    // the same generators on the host (what from_label returns to a caller that keeps them itself)
+    static std::vector<reef_affine> from_label(const std::string &label, size_t n, const reef_keygen_params &kp, bool kp_is_mont = false) {
+        std::vector<reef_affine> out(n);
+        check(reef_derive_generators(CURVE, (const uint8_t *)label.data(), label.size(), n, &kp, kp_is_mont, out.data(), REEF_HOST), "reef_derive_generators");
+        return out;
     }
     ~CommitmentGens() { reef_msm_ctx_destroy(ctx_); }
     CommitmentGens(const CommitmentGens &) = delete;
@@ -242,6 +268,66 @@ class SumCheck {
   private:
     reef_sc_ctx *sc_ = nullptr;
     size_t ell_;
+};
+
+// The reference's MerkleCommitment<F> (src/backend/merkle_tree.rs:11-16): `commitment` (the root), `tree` (the levels, the leaves' parents first)
+// and `doc`.  The tree is built on the GPU -- on one device, or in blocks over `devices` (reef_merkle_commit_devices) --; path_wits / make_wits
+// (:116-190) are look-ups in it on the host, as in the reference.  The Poseidon constants are the caller's (neptune's, on the Rust side).
+struct MerkleWit {
+    bool l_or_r;          // true: the node on the path is the LEFT child
+    bool has_idx;         // leaf level only (the reference's Option): opposite_idx is the sibling's document index (0 when it is missing)
+    uint64_t opposite_idx;
+    reef_fe opposite;     // the sibling's value, canonical (zero when it is missing)
+};
+template <int CURVE> class MerkleCommitment {
+  public:
+    MerkleCommitment(const std::vector<uint32_t> &document, const reef_poseidon_params &pc, bool pc_is_mont = false, const std::vector<int> &devices = {})
+        : doc(document) {
+        if (doc.empty()) throw std::invalid_argument("MerkleCommitment::new: empty document");     // the reference indexes an empty level: a panic
+        std::vector<reef_fe> flat(reef_merkle_nodes(doc.size()));
+        if (devices.empty())
+            check(reef_merkle_commit(CURVE, &pc, doc.data(), doc.size(), REEF_HOST, pc_is_mont, flat.data(), REEF_HOST, &commitment), "reef_merkle_commit");
+        else
+            check(reef_merkle_commit_devices(CURVE, &pc, doc.data(), doc.size(), pc_is_mont, devices.data(), devices.size(), flat.data(), &commitment, nullptr),
+                  "reef_merkle_commit_devices");
+        size_t m = (doc.size() + 1) / 2, off = 0;
+        for (;;) {
+            tree.emplace_back(flat.begin() + off, flat.begin() + off + m);
+            off += m;
+            if (m <= 1) break;
+            m = (m + 1) / 2;
+        }
+    }
+    // merkle_tree.rs:128-190
+    std::vector<MerkleWit> path_wits(size_t idx) const {
+        if (idx >= doc.size()) throw std::out_of_range("path_wits: idx < doc.len()");
+        const reef_fe zero = {};
+        auto sym = [](uint32_t v) { return reef_fe{{v, 0, 0, 0}}; };
+        std::vector<MerkleWit> w;
+        if (idx % 2 == 0) {
+            if (idx + 1 >= doc.size()) w.push_back({true, true, 0, zero});
+            else w.push_back({true, true, idx + 1, sym(doc[idx + 1])});
+        } else {
+            w.push_back({false, true, idx - 1, sym(doc[idx - 1])});
+        }
+        size_t quo = idx / 2;
+        for (size_t h = 0; h + 1 < tree.size(); ++h) {
+            if (quo % 2 == 0) w.push_back({true, false, 0, quo + 1 >= tree[h].size() ? zero : tree[h][quo + 1]});
+            else w.push_back({false, false, 0, tree[h][quo - 1]});
+            quo /= 2;
+        }
+        return w;
+    }
+    // merkle_tree.rs:116-126
+    std::vector<std::vector<MerkleWit>> make_wits(const std::vector<size_t> &m_lookups) const {
+        std::vector<std::vector<MerkleWit>> wits;
+        for (size_t q : m_lookups) wits.push_back(path_wits(q));
+        return wits;
+    }
+
+    reef_fe commitment = {};
+    std::vector<std::vector<reef_fe>> tree;
+    std::vector<uint32_t> doc;
 };
 
 }  // namespace reef_provider

@@ -4,7 +4,7 @@ side); this module only marshals them."""
 from __future__ import annotations
 
 import ctypes
-from typing import Optional, List, Sequence, Tuple
+from typing import List, NamedTuple, Optional, Sequence, Tuple
 
 import numpy as np
 
@@ -86,3 +86,57 @@ def commit_arrays(curve, doc: np.ndarray, width: int, full_rounds: int, partial_
                 break
             m_ = (m_ + 1) // 2
     return array_to_ints(root)[0], levels
+
+
+class MerkleWit(NamedTuple):
+    """src/backend/merkle_tree.rs:18-22: one step of an opening path."""
+    l_or_r: bool                      # True: the node on the path is the LEFT child
+    opposite_idx: Optional[int]       # leaf level only: the sibling's document index (0 when the sibling is missing)
+    opposite: int                     # the sibling's value (0 when missing)
+
+
+class MerkleCommitment:
+    """Mirror of the reference's `MerkleCommitment<F>` (src/backend/merkle_tree.rs:11-16): `commitment` (the root), `tree` (the levels,
+    leaves' parents first) and `doc`, with the openings Reef takes from it -- `path_wits(idx)` (:128-190) and `make_wits(lookups)`
+    (:116-126).  `new` builds the tree on the GPU (reef_merkle_commit, or reef_merkle_commit_devices with `devices`); the openings are
+    look-ups in that tree on the host, as in the reference.  Levels are kept as (m, 4) uint64 arrays of canonical limbs: a 64 MiB
+    document has 2^27 nodes."""
+
+    def __init__(self, doc, commitment: int, levels: Sequence[np.ndarray]):
+        self.doc = np.ascontiguousarray(np.asarray(doc, dtype=np.uint32))
+        self.commitment = int(commitment)
+        self.tree = [np.asarray(lv, dtype=np.uint64).reshape(-1, 4) for lv in levels]
+
+    @classmethod
+    def new(cls, curve, doc, width: int, full_rounds: int, partial_rounds: int, round_constants: Sequence[int], mds: Sequence[Sequence[int]],
+            tag_leaf: int, tag_node: int, devices: Optional[Sequence[int]] = None) -> "MerkleCommitment":
+        """MerkleCommitment::new(&doc, &pc) (merkle_tree.rs:25-80); the Poseidon constants are the caller's (neptune's, on the Rust side)."""
+        d = np.ascontiguousarray(np.asarray(doc, dtype=np.uint32))
+        if d.shape[0] == 0:
+            raise ValueError("empty document")          # the reference indexes next_level[0] of an empty level: a panic
+        root, levels = commit_arrays(curve, d, width, full_rounds, partial_rounds, round_constants, mds, tag_leaf, tag_node, want_tree=True, devices=devices)
+        return cls(d, root, levels)
+
+    def _node(self, h: int, i: int) -> int:
+        row = self.tree[h][i]
+        return int(row[0]) | int(row[1]) << 64 | int(row[2]) << 128 | int(row[3]) << 192
+
+    def path_wits(self, idx: int) -> List[MerkleWit]:
+        n = self.doc.shape[0]
+        if not 0 <= idx < n:
+            raise IndexError(f"document index {idx} out of range (the reference asserts idx < doc.len())")
+        if idx % 2 == 0:
+            wit = MerkleWit(True, 0, 0) if idx + 1 >= n else MerkleWit(True, idx + 1, int(self.doc[idx + 1]))
+        else:
+            wit = MerkleWit(False, idx - 1, int(self.doc[idx - 1]))
+        wits, quo = [wit], idx // 2
+        for h in range(len(self.tree) - 1):
+            if quo % 2 == 0:
+                wits.append(MerkleWit(True, None, 0 if quo + 1 >= self.tree[h].shape[0] else self._node(h, quo + 1)))
+            else:
+                wits.append(MerkleWit(False, None, self._node(h, quo - 1)))
+            quo //= 2
+        return wits
+
+    def make_wits(self, m_lookups: Sequence[int]) -> List[List[MerkleWit]]:
+        return [self.path_wits(int(q)) for q in m_lookups]

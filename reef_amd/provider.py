@@ -8,9 +8,11 @@ reference's call sites and so that a maintainer can see what each Rust method ma
     reference call site (eniac/Reef)                         here
     -------------------------------------------------------  --------------------------------
     G::vartime_multiscalar_mul(scalars, bases)        [R]    vartime_multiscalar_mul(...)
-    CommitmentGens::<G>::new(label, n) / new_with_..  [R]    CommitmentGens(curve, bases [, h])
-        (framework.rs:297-303, commitment.rs:176-180)         (bases are *given*: key derivation
-                                                               from_label is row N1 of SURVEY 8f)
+    CommitmentGens::<G>::new(label, n) / new_with_..  [R]    CommitmentGens.new(curve, label, n, <hash-to-curve constants>) /
+        (framework.rs:297-303, commitment.rs:176-180)         .new_with_blinding_gen(.., h): derived on the GPU (row N1);
+                                                               CommitmentGens(curve, bases [, h]) for bases that are given
+    MerkleCommitment::new(&doc, &pc), path_wits, make_wits   reef_amd.merkle.MerkleCommitment (row N4: tree on the GPU, openings
+        (merkle_tree.rs:25-190)                               looked up on the host)
     CE::commit(&gens, &v, &blind)                      [R]    CommitmentGens.commit(v, blind)
         (commitment.rs:350,361,422,430)
     gens.fold(w1, w2) / split_at / combine             [R]    CommitmentGens.fold / split_at / combine  (the points), or
@@ -96,6 +98,21 @@ class CommitmentGens:
         self._precompute = precompute
         self._window_bits = window_bits
         self._ctx: Optional[msm.MsmContext] = None
+
+    @classmethod
+    def new(cls, curve, label: bytes, n: int, *, a: int, b: int, z: int, iso: Sequence[int], dst: bytes, little_endian: bool = False,
+            h: Optional[np.ndarray] = None, **kw) -> "CommitmentGens":
+        """CommitmentGens::new(label, n) [R] (src/backend/framework.rs:297-303, commitment.rs:146-149, :176-180): the n generators are
+        derived from the label on the GPU (row N1, reef_derive_generators: SHAKE256 stream on the host, the 2n maps to the curve and the
+        batch normalisation on the device).  pasta_curves' hash-to-curve constants (a, b, z of the isogenous curve, the 13 isogeny
+        coefficients, the domain separation string) are inputs: they live in an un-vendored crate."""
+        from . import keygen
+        return cls(curve, keygen.derive_generators(curve, label, n, a, b, z, iso, dst, little_endian), h, **kw)
+
+    @classmethod
+    def new_with_blinding_gen(cls, curve, label: bytes, n: int, blinding_gen: np.ndarray, **kw) -> "CommitmentGens":
+        """The fork's CommitmentGens::new_with_blinding_gen(label, n, &h) [R] (commitment.rs:176-180): generators from the label, h given."""
+        return cls.new(curve, label, n, h=blinding_gen, **kw)
 
     def __len__(self) -> int:
         return self.bases.shape[0]

@@ -72,3 +72,26 @@ def test_gpu_matches_committed_fixture(gpu_lib):
         raw = keygen.derive_generators(case["curve"], bytes.fromhex(case["label_hex"]), len(case["points"]), k.a, k.b, k.z, k.iso, k.dst, k.little_endian)
         got = keygen.points_to_ints(case["curve"], raw)
         assert [[hex(p[0]), hex(p[1])] for p in got] == case["points"]
+
+
+@pytest.mark.parametrize("curve", ("pallas", "vesta"))
+def test_commitment_gens_new_from_a_label(curve, gpu_lib):
+    """CommitmentGens::new(label, n) / new_with_blinding_gen as Reef calls them (framework.rs:297-303, commitment.rs:176-180) through the
+    provider mirror: the generators are the oracle's from_label, and a commitment over them (with and without a blind) is the oracle's."""
+    from oracle import pasta_ref as R
+    from reef_amd import keygen, provider
+    k = K.standin_params(curve)
+    cid = 0 if curve == "pallas" else 1
+    n = 300
+    kw = dict(a=k.a, b=k.b, z=k.z, iso=k.iso, dst=k.dst, little_endian=k.little_endian)
+    gens = provider.CommitmentGens.new(curve, b"reef ck", n, **kw)
+    assert len(gens) == n and keygen.points_to_ints(curve, gens.bases) == K.from_label(b"reef ck", n, k)
+    v = R.gen_scalars(cid, 99, n, kind=1)
+    assert gens.commit(v).compress() == R.compress(cid, R.msm_pippenger(cid, gens.bases, v))
+    h = R.gen_bases_ap(cid, 0xB11D, 1, 1)[0].copy()
+    blind = R.gen_scalars(cid, 100, 1)
+    gb = provider.CommitmentGens.new_with_blinding_gen(curve, b"reef ck", n, h, **kw)
+    assert np.array_equal(gb.bases, gens.bases)
+    assert gb.commit(v, blind).compress() == R.compress(cid, R.row_msm(cid, gens.bases, v, 1, n, h=h, blinds=blind))
+    gens.close()
+    gb.close()

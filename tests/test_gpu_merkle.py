@@ -162,3 +162,22 @@ def test_tree_in_blocks_over_several_devices_is_the_same_tree(members, gpu_lib):
     assert root_only == root1 and none == []
     with pytest.raises(msm.ReefError):
         merkle.commit_arrays("pallas", doc[:10], p.t, p.rf, p.rp, p.rc, p.mds, p.tag_leaf, p.tag_node, devices=[0, 99])
+
+
+@pytest.mark.parametrize("n,devices", [(7, None), (64, None), (1001, None), (1001, [0, 0, 0]), (4097, [0, 0])])
+def test_merkle_commitment_mirror_builds_on_the_gpu(n, devices, gpu_lib):
+    """MerkleCommitment::new(&doc, &pc) as Reef calls it (merkle_tree.rs:25), then make_wits over lookups (:116): the tree is the GPU's,
+    the openings are the product's host look-ups; every path recomputes the commitment with the oracle's sponge, as the reference's
+    make_mt test does (:222-249), and the commitment is the oracle's."""
+    from reef_amd.merkle import MerkleCommitment
+    p = M.standin_params()
+    doc = [(31 * i + 7) % 131 for i in range(n)]
+    mc = MerkleCommitment.new("pallas", doc, p.t, p.rf, p.rp, p.rc, p.mds, p.tag_leaf, p.tag_node, devices=devices)
+    eroot, etree = M.commit(doc, p)
+    assert mc.commitment == eroot and [lv.shape[0] for lv in mc.tree] == [len(lv) for lv in etree]
+    lookups = sorted({0, 1, n // 2, n - 2 if n > 1 else 0, n - 1})
+    for q, wits in zip(lookups, mc.make_wits(lookups)):
+        assert [tuple(w) for w in wits] == [tuple(w) for w in M.path_wits(doc, etree, q)]
+        assert M.root_from_path(doc, q, wits, p) == mc.commitment
+    with pytest.raises(ValueError):
+        MerkleCommitment.new("pallas", [], p.t, p.rf, p.rp, p.rc, p.mds, p.tag_leaf, p.tag_node)

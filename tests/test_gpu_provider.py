@@ -247,6 +247,30 @@ def test_cpp_provider_mirror_matches_oracle(gpu_lib, cref):
         S.linear_mle_fold(t, e, 3, i, rs[i - 1])
     assert got["sumcheck_final"] == t[0].to_bytes(32, "little").hex()
     assert got["error_throws"] is True
+    # CommitmentGens::new(label, n) / new_with_blinding_gen: generators from the label (stand-in constants = the oracle's), commitments over them
+    from oracle import keygen_oracle as KO, merkle_oracle as MO
+    from reef_amd import keygen
+    kp = KO.standin_params("pallas")
+    ln = 300
+    raw = keygen.derive_generators("pallas", b"reef ck", ln, kp.a, kp.b, kp.z, kp.iso, kp.dst)
+    assert keygen.points_to_ints("pallas", raw) == KO.from_label(b"reef ck", ln, kp)
+    assert got["label_gens"] == raw[:3].tobytes().hex()
+    lv = cref.gen_scalars(0, 99, ln, kind=1)
+    assert got["label_commit"] == cref.compress(0, cref.msm_pippenger(0, raw, lv, threads=4)).hex()
+    assert got["label_commit_blind"] == cref.compress(0, cref.row_msm(0, raw, lv, 1, ln, h=h, blinds=blind)).hex()
+    # MerkleCommitment::new + path_wits on the reference's own document and on a longer one built in blocks
+    pp = MO.standin_params()
+
+    def path(doc, tree, q):
+        return [[bool(lr), idx, opp.to_bytes(32, "little").hex()] for lr, idx, opp in MO.path_wits(doc, tree, q)]
+    doc7 = [2, 3, 4, 5, 6, 7, 8]
+    root7, tree7 = MO.commit(doc7, pp)
+    assert got["merkle_root"] == root7.to_bytes(32, "little").hex() and got["merkle_levels"] == len(tree7)
+    assert got["merkle_path6"] == path(doc7, tree7, 6) and got["merkle_path3"] == path(doc7, tree7, 3)
+    long_doc = [(31 * i + 7) % 131 for i in range(1001)]
+    rootl, treel = MO.commit(long_doc, pp)
+    assert got["merkle_blocks_root"] == rootl.to_bytes(32, "little").hex() and got["merkle_blocks_path500"] == path(long_doc, treel, 500)
+    assert got["merkle_oob_throws"] is True
 
 
 

@@ -59,3 +59,32 @@ def test_oracle_matches_committed_fixture():
         p = M.standin_params(M.Q if case["scalar_field_of"] == "pallas" else M.P, 5, case["rf"], case["rp"])
         root, tree = M.commit(case["doc"], p)
         assert hex(root) == case["root"] and [len(l) for l in tree] == case["level_sizes"] and hex(tree[0][0]) == case["first_leaf"]
+
+
+def test_product_side_openings_follow_the_reference():
+    """reef_amd.merkle.MerkleCommitment mirrors the reference's struct (merkle_tree.rs:11-16) and its openings (path_wits :128-190, make_wits
+    :116-126), which are look-ups in the tree on the host.  Here the tree comes from the oracle (no GPU): every path equals the oracle's
+    restatement and recomputes the commitment as the reference's own test does (make_mt, :209-257); odd levels, a missing right sibling
+    and a single symbol included."""
+    import pytest
+    from oracle import merkle_oracle as MO
+    from reef_amd.merkle import MerkleCommitment, MerkleWit
+    from reef_amd.sumcheck import ints_to_array
+    p = MO.standin_params()
+    for n in (1, 2, 3, 4, 5, 7, 8, 9, 16, 17, 31):
+        doc = [(i * 7 + 3) % 131 for i in range(n)]
+        root, tree = MO.commit(doc, p)
+        mc = MerkleCommitment(doc, root, [ints_to_array(lv) for lv in tree])
+        assert mc.commitment == root and len(mc.tree) == len(tree)
+        for q in range(n):
+            w = mc.path_wits(q)
+            assert all(isinstance(x, MerkleWit) for x in w) and len(w) == len(tree)
+            assert [tuple(x) for x in w] == [tuple(x) for x in MO.path_wits(doc, tree, q)], (n, q)
+            assert MO.root_from_path(doc, q, w, p) == mc.commitment
+        assert mc.make_wits([0, n - 1]) == [mc.path_wits(0), mc.path_wits(n - 1)]
+        with pytest.raises(IndexError):
+            mc.path_wits(n)                        # the reference asserts idx < doc.len()
+    doc = [2, 3, 4, 5, 6, 7, 8]                    # the reference's own document (merkle_tree.rs:214)
+    root, tree = MO.commit(doc, p)
+    first = MerkleCommitment(doc, root, [ints_to_array(lv) for lv in tree]).path_wits(6)[0]
+    assert first == MerkleWit(True, 0, 0)          # the last symbol of an odd document has no right sibling: (Some(0), 0), :133-139
