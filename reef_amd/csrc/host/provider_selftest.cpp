@@ -106,6 +106,23 @@ int main() {
             else sc.fold(i, rs[i - 1]);
         }
         out += "], \"sumcheck_final\": \"" + fhex(sc.final_value()) + "\", ";
+        // ---- the same step through linear_mle_product (the reference's one-call round), with a transcript that returns fixed challenges and records what it absorbed
+        {
+            sc.start_step();
+            sc.gen_eq_table({small(3), small(9), small(27), small(81)}, {2, 1, 7}, {small(5), small(3), small(2)});
+            size_t round = 0;
+            std::string absorbed = "[";
+            auto transcript = [&](const std::array<reef_fe, 3> &q) {
+                absorbed += std::string(round ? ", " : "") + "[\"" + fhex(q[0]) + "\", \"" + fhex(q[1]) + "\", \"" + fhex(q[2]) + "\"]";
+                return rs[round++];
+            };
+            out += "\"lmp\": [";
+            for (size_t i = 1; i <= 3; ++i) {
+                const auto t4 = sc.linear_mle_product(i, transcript);
+                out += std::string(i > 1 ? ", " : "") + "[\"" + fhex(t4[0]) + "\", \"" + fhex(t4[1]) + "\", \"" + fhex(t4[2]) + "\", \"" + fhex(t4[3]) + "\"]";
+            }
+            out += "], \"lmp_absorbed\": " + absorbed + "], \"lmp_final\": \"" + fhex(sc.final_value()) + "\", ";
+        }
         // ---- CommitmentGens::new(label, n) / new_with_blinding_gen: the key derived from a label on the GPU (row N1), commitments over it
         {
             reef_keygen_params kp;

@@ -240,10 +240,11 @@ class SumCheck {
     SumCheck(const SumCheck &) = delete;
     SumCheck &operator=(const SumCheck &) = delete;
 
-    void set_table(const reef_fe *values, size_t n, int loc = REEF_HOST) { check(reef_sc_set_table(sc_, 0, values, n, loc), "reef_sc_set_table"); }
-    void start_step() { check(reef_sc_reset_table(sc_), "reef_sc_reset_table"); }   // every folding step starts from the unfolded table
+    void set_table(const reef_fe *values, size_t n, int loc = REEF_HOST) { have_next_ = false; check(reef_sc_set_table(sc_, 0, values, n, loc), "reef_sc_set_table"); }
+    void start_step() { have_next_ = false; check(reef_sc_reset_table(sc_), "reef_sc_reset_table"); }   // every folding step starts from the unfolded table
     void gen_eq_table(const std::vector<reef_fe> &rs, const std::vector<uint32_t> &qs, const std::vector<reef_fe> &last_q) {
         if (rs.size() != qs.size() + 1 || last_q.size() != ell_) throw std::logic_error("gen_eq_table: |rs| = |qs| + 1, |last_q| = ell");
+        have_next_ = false;
         check(reef_sc_gen_eq_table(sc_, rs.data(), qs.data(), qs.size(), last_q.data(), ell_), "reef_sc_gen_eq_table");
     }
     // round i in 1..ell: (xsq, x, con)
@@ -259,6 +260,24 @@ class SumCheck {
         check(reef_sc_fold_and_next_coeffs(sc_, (size_t)1 << (ell_ - i), &r, g.data()), "reef_sc_fold_and_next_coeffs");
         return g;
     }
+    // The whole of the reference's linear_mle_product(table_t, table_eq, ell, i, sponge) (r1cs_helper.rs:441-506) on the resident tables: the round's
+    // sums, absorb (con, x, xsq) in that order, squeeze the challenge, fold both tables; returns {r_i, xsq, x, con} like the reference.  `transcript`
+    // is the caller's sponge: given {con, x, xsq} (canonical) it returns the challenge (neptune's SpongeAPI absorb(3) + squeeze(1) on the Rust side).
+    // Driven round after round as r1cs.rs:2318-2385 does, each round is one pass over the tables (the fold of round i yields round i + 1's sums).
+    template <class Transcript> std::array<reef_fe, 4> linear_mle_product(size_t i, Transcript &&transcript) {
+        const std::array<reef_fe, 3> g = (have_next_ && next_round_ == i) ? next_ : round_coeffs(i);      // {xsq, x, con}
+        const std::array<reef_fe, 3> query = {g[2], g[1], g[0]};
+        const reef_fe r = transcript(query);
+        have_next_ = false;
+        if (i < ell_) {
+            next_ = fold_and_next_coeffs(i, r);
+            next_round_ = i + 1;
+            have_next_ = true;
+        } else {
+            fold(i, r);
+        }
+        return {r, g[0], g[1], g[2]};
+    }
     reef_fe final_value() {   // prover_mle_partial_eval(table, sc_rs) after the last fold (r1cs.rs:2379-2385)
         reef_fe v;
         check(reef_sc_read(sc_, 0, 1, &v), "reef_sc_read");
@@ -268,6 +287,9 @@ class SumCheck {
   private:
     reef_sc_ctx *sc_ = nullptr;
     size_t ell_;
+    std::array<reef_fe, 3> next_ = {};     // sums of the round after the last linear_mle_product, if that call produced them
+    size_t next_round_ = 0;
+    bool have_next_ = false;
 };
 
 // The reference's MerkleCommitment<F> (src/backend/merkle_tree.rs:11-16): `commitment` (the root), `tree` (the levels, the leaves' parents first)

@@ -62,9 +62,11 @@ class SumCheck:
         """values: list of ints, or an (n, 4) uint64 array of canonical limbs."""
         arr = values if isinstance(values, np.ndarray) else ints_to_array(values)
         arr = np.ascontiguousarray(arr, dtype=np.uint64)
+        self._pending = None
         check(self._lib.reef_sc_set_table(self._h, which, arr.ctypes.data, arr.shape[0], REEF_HOST))
 
     def set_table_device(self, which: int, ptr: int, n: int) -> None:
+        self._pending = None
         check(self._lib.reef_sc_set_table(self._h, which, ptr, n, REEF_DEVICE))
 
     def gen_eq_table(self, rs: Sequence[int], qs: Sequence[int], last_q: Sequence[int]) -> None:
@@ -72,6 +74,7 @@ class SumCheck:
         assert len(rs) == len(qs) + 1 and len(last_q) == self.ell
         a, lq = ints_to_array(rs), ints_to_array(last_q)
         q = np.ascontiguousarray(np.array(list(qs) + [0], dtype=np.uint32))
+        self._pending = None
         check(self._lib.reef_sc_gen_eq_table(self._h, a.ctypes.data, q.ctypes.data, len(qs), lq.ctypes.data, self.ell))
 
     def round_coeffs(self, i: int) -> Tuple[int, int, int]:
@@ -84,15 +87,34 @@ class SumCheck:
     def fold(self, i: int, r: int) -> None:
         """Second half of linear_mle_product for round i with the host's challenge r."""
         rr = ints_to_array([r])
+        self._pending = None
         check(self._lib.reef_sc_fold(self._h, 1 << (self.ell - i), rr.ctypes.data))
 
     def fold_and_next_coeffs(self, i: int, r: int) -> Tuple[int, int, int]:
         """fold(i, r) fused with round_coeffs(i + 1): one pass over the tables (i < ell)."""
         rr = ints_to_array([r])
         out = np.zeros((3, 4), dtype=np.uint64)
+        self._pending = None
         check(self._lib.reef_sc_fold_and_next_coeffs(self._h, 1 << (self.ell - i), rr.ctypes.data, out.ctypes.data))
         xsq, x, con = array_to_ints(out)
         return xsq, x, con
+
+    def linear_mle_product(self, i: int, sponge) -> Tuple[int, int, int, int]:
+        """The whole of the reference's linear_mle_product(table_t, table_eq, ell, i, sponge) (src/backend/r1cs_helper.rs:441-506) on the
+        resident tables: the round's sums, absorb (con, x, xsq) in that order (:478-482), squeeze the challenge (:485-488), fold both
+        tables.  Returns (r_i, xsq, x, con) like the reference.  `sponge` is the caller's transcript (absorb(list of ints), squeeze(n) ->
+        list: the SpongeAPI calls Reef makes; neptune's on the Rust side): the challenge is the host's.  Rounds driven one after the
+        other as r1cs.rs:2318-2385 does cost one pass over the tables each: the fold of round i also yields round i + 1's sums."""
+        pending = getattr(self, "_pending", None)
+        xsq, x, con = pending[1] if pending is not None and pending[0] == i else self.round_coeffs(i)
+        sponge.absorb([con, x, xsq])
+        r_i = sponge.squeeze(1)[0]
+        if i < self.ell:
+            self._pending = (i + 1, self.fold_and_next_coeffs(i, r_i))
+        else:
+            self.fold(i, r_i)
+            self._pending = None
+        return r_i, xsq, x, con
 
     def read(self, which: int, count: int) -> List[int]:
         out = np.zeros((count, 4), dtype=np.uint64)
@@ -101,6 +123,7 @@ class SumCheck:
 
     def reset_table(self) -> None:
         """T <- the table as last set (start of the next folding step)."""
+        self._pending = None
         check(self._lib.reef_sc_reset_table(self._h))
 
     def sync(self) -> None:

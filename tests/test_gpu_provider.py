@@ -247,6 +247,14 @@ def test_cpp_provider_mirror_matches_oracle(gpu_lib, cref):
         S.linear_mle_fold(t, e, 3, i, rs[i - 1])
     assert got["sumcheck_final"] == t[0].to_bytes(32, "little").hex()
     assert got["error_throws"] is True
+    # the same step through the C++ mirror's linear_mle_product: (r_i, xsq, x, con) per round, (con, x, xsq) absorbed in that order (r1cs_helper.rs:478-482)
+    hx = lambda v: v.to_bytes(32, "little").hex()
+    t, e = list(evals), S.gen_eq_table(claims, qs, last_q)
+    for i in range(1, 4):
+        xsq, x, con = S.linear_mle_coeffs(t, e, 3, i)
+        assert got["lmp"][i - 1] == [hx(rs[i - 1]), hx(xsq), hx(x), hx(con)] and got["lmp_absorbed"][i - 1] == [hx(con), hx(x), hx(xsq)]
+        S.linear_mle_fold(t, e, 3, i, rs[i - 1])
+    assert got["lmp_final"] == hx(t[0])
     # CommitmentGens::new(label, n) / new_with_blinding_gen: generators from the label (stand-in constants = the oracle's), commitments over them
     from oracle import keygen_oracle as KO, merkle_oracle as MO
     from reef_amd import keygen

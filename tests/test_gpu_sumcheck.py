@@ -595,3 +595,39 @@ def test_stress_reference_transcript_is_the_oracles(gpu_lib):
         linear_mle_fold(t, e, ell, i, chal[i - 1])
     want.append(t[0])
     assert got == want
+
+
+@pytest.mark.parametrize("ell,n_t", [(3, 8), (11, 1500)])
+def test_linear_mle_product_drives_a_step_like_the_reference(ell, n_t, gpu_lib):
+    """The product-side SumCheck.linear_mle_product(i, sponge) is the reference's one-call round (r1cs_helper.rs:441-506): sums, absorb
+    (con, x, xsq), squeeze r_i, fold.  A whole step driven as r1cs.rs:2318-2385 drives it, with the same sponge (oracle/sumcheck_oracle.py:
+    Sponge, the SpongeAPI calls Reef makes) on both sides: the transcripts (r_i, xsq, x, con) are the oracle's round for round, twice in a row
+    (a second folding step after reset_table), and the final value is verifier_mle_eval at the challenges."""
+    from oracle import merkle_oracle as MO
+    from oracle.sumcheck_oracle import Sponge, linear_mle_product
+    from reef_amd.sumcheck import SumCheck
+    rng = SplitMix64(ell * 1000 + n_t)
+    table = [2, 3, 5, 7, 9, 13, 17, 19] if ell == 3 else [uniform_scalar(rng, Q) for _ in range(n_t)]
+    pp = MO.standin_params()
+    with SumCheck("pallas", ell) as sc:
+        sc.set_table(0, table)
+        for step in range(2):
+            nq = 3 + step
+            claims = [uniform_scalar(rng, Q) for _ in range(nq + 1)]
+            qs = [rng.next() % (1 << ell) for _ in range(nq)]
+            last_q = [uniform_scalar(rng, Q) for _ in range(ell)]
+            if step:
+                sc.reset_table()
+            sc.gen_eq_table(claims, qs, last_q)
+            t = list(table) + [0] * ((1 << ell) - len(table))
+            e = gen_eq_table(claims, qs, last_q)
+            sp_gpu, sp_ref = Sponge(pp, 0x5EED + step), Sponge(pp, 0x5EED + step)
+            sp_gpu.absorb(claims)
+            sp_ref.absorb(claims)                               # Absorb(k) of the IO pattern, before the rounds (r1cs.rs:2260-2284)
+            rs = []
+            for i in range(1, ell + 1):
+                got = sc.linear_mle_product(i, sp_gpu)
+                assert got == linear_mle_product(t, e, ell, i, sp_ref), (step, i)
+                rs.append(got[0])
+            assert sc.read(0, 1)[0] == t[0] == verifier_mle_eval(list(table) + [0] * ((1 << ell) - len(table)), rs)
+            assert sp_gpu.state == sp_ref.state
