@@ -68,3 +68,9 @@ def bound_rows(curve, z: Sequence[int] | np.ndarray, point: Sequence[int], left_
 def evaluate(curve, z, point: Sequence[int]) -> int:
     """doc_poly.evaluate(point) (commitment.rs:357) / verifier_mle_eval(table, point) (:236)."""
     return bound_rows(curve, z, point)[1]
+
+
+def verifier_mle_eval(table, q: Sequence[int], curve="pallas") -> int:
+    """The reference's verifier_mle_eval(table, q) (src/backend/r1cs_helper.rs:637-641; called at commitment.rs:236 on the document): the
+    multilinear extension of `table` at q, q[0] pairing with the most significant index bit.  Over Fq = the scalar field of Pallas, as Reef's."""
+    return evaluate(curve, table, q)

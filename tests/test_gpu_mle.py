@@ -26,6 +26,7 @@ def test_reference_kat_on_gpu(gpu_lib):
         e = x[0] * 4 + x[1] * 2 + x[2]
         assert mle.evaluate("pallas", table, list(x)) == table[e]
         assert mle.evaluate("pallas", np.array(table, dtype=np.uint8), list(x)) == table[e]
+        assert mle.verifier_mle_eval(table, list(x)) == table[e]            # under the reference's own name (r1cs_helper.rs:637)
 
 
 @pytest.mark.parametrize("name", ["pallas", "vesta"])
