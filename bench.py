@@ -62,6 +62,9 @@ def parse():
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--cpu-seconds", type=float, default=12.0)
     p.add_argument("--no-check", action="store_true")
+    p.add_argument("--allow-experiment", action="store_true",
+                   help="report `value` although the library loaded is the +experiment build (REEF_MSM_LIB=.../libreef_msm_exp.so: A/B runs); without it the "
+                        "bench refuses: the measured artefact is the release build (reef_amd/_lib/libreef_msm.so)")
     p.add_argument("--no-replay", action="store_true", help="skip the replay of Reef's own MSM sequence (config.replay_cfg3) after the timed region")
     p.add_argument("--exercise-collective", action="store_true",
                    help="with --gpus 1: run the N > 1 code path (process group of one rank, all_gather + on-device combine) "
@@ -259,6 +262,9 @@ def replay_leg(cfg="cfg3", with_tables=True):
                                         "depends on what else the process has alive (profiles/r04_concurrency_bisect.txt: 9.6 -> 6.0 ms in this process)",
                 "sumcheck_ms_per_step": g.get("sumcheck_ms_per_step"), "sumcheck_table_log": g.get("sumcheck_table_log"),
                 "total_prove_msm_ms": g["total_prove_msm_ms"], "total_prove_gpu_ms": g["total_prove_gpu_ms"], "setup_ms": g["setup_ms"],
+                "setup_first_ms": g.get("setup_first_ms"), "setup_path": g.get("setup_path"),
+                # Reef re-derives its keys on every --prove (framework.rs:115,297-303): set-up IS prove time, so the figure to quote is this one
+                "prove_gpu_incl_setup_ms": g["setup_ms"] + g["total_prove_gpu_ms"],
                 "commitments_checked_against_dlog": g["commitments_checked_against_dlog"],
                 "scalars": "host memory in, commitments back to the host (PCIe-inclusive)", "ipa": g["ipa"]})
     if with_tables:
@@ -267,7 +273,14 @@ def replay_leg(cfg="cfg3", with_tables=True):
             out["byte_tables"] = {"fold_ms_per_step": t["ms_per_step"], "ipa_ms": t["ipa_pallas_ms"] + t["ipa_vesta_ms"],
                                   "three_arguments_concurrently_ms": t.get("three_arguments_concurrently_ms"),
                                   "total_prove_msm_ms": t["total_prove_msm_ms"], "setup_ms": t["setup_ms"],
+                                  "prove_gpu_incl_setup_ms": t["setup_ms"] + t["total_prove_gpu_ms"],
                                   "commitments_checked_against_dlog": t["commitments_checked_against_dlog"]}
+            # the byte tables cost set-up and save time per folding step: from how many steps on does a run that builds them come out ahead?
+            saved_per_step = g["ms_per_step"] - t["ms_per_step"]
+            fixed = (t["setup_ms"] - g["setup_ms"]) - ((g["total_prove_gpu_ms"] - g["fold_steps_ms"]) - (t["total_prove_gpu_ms"] - t["fold_steps_ms"]))
+            out["byte_tables"]["break_even_steps"] = (max(0.0, fixed) / saved_per_step) if saved_per_step > 0 else None
+            out["byte_tables"]["break_even_note"] = ("folding steps after which building the byte tables has paid for itself: (extra set-up - what the final SNARK saves) / "
+                                                     "(ms saved per step); this config folds %d times" % g["steps"])
         except Exception as e:
             out["byte_tables"] = {"error": str(e)}
     return out
@@ -608,6 +621,7 @@ def main():
     import torch
     import torch.distributed as dist
     from reef_amd import msm
+    from reef_amd import _ffi as _ffi_mod
 
     ndev = max(1, msm.device_count())
     dev_index = local_rank % ndev          # one rank per GPU; (gloo debug runs may share a device)
@@ -644,7 +658,13 @@ def main():
     bases = msm.gen_bases(a.curve, k0 + owner * n * d, d, n, device=True)
     B = a.batch if not multi else 1
     scalars = msm.gen_scalars(a.curve, seed, n * B, kind=kind, mont=True, device=True)
-    ctx0 = msm.MsmContext(a.curve, bases, n, window_bits=a.window_bits, bucket_groups=groups, chunk=a.chunk)
+    library = _ffi_mod.load().reef_version().decode()
+    if "+experiment" in library and not a.allow_experiment:
+        raise SystemExit(f"bench.py measures the release build; the library loaded is {library!r} ({_ffi_mod.LIB_PATH}): unset REEF_MSM_LIB or pass --allow-experiment")
+    torch.cuda.synchronize()
+    t_key = time.perf_counter()
+    ctx0 = msm.MsmContext(a.curve, bases, n, window_bits=a.window_bits, bucket_groups=groups, chunk=a.chunk)   # returns with the tables built
+    key_build_ms = (time.perf_counter() - t_key) * 1e3
     if by_windows:
         ctx0.set_window_split(rank, max(world, 1))
     _diag("before the contexts")
@@ -738,6 +758,7 @@ def main():
     single = None
     host_ms = None
     host_pageable = None
+    plain_key = None
 
     # ---- N > 1: the timed region's own result is checked BEFORE any side leg runs, and the side legs run under a deadline ----
     # Everything from here to the end of the run has never met more than one physical GPU (RCCL on > 1 rank, peer copies between
@@ -812,7 +833,10 @@ def main():
             "steps": a.steps, "warmup": a.warmup, "ms_per_step": elapsed / a.steps * 1e3, "higher_is_better": True,
             "scaling": "strong" if by_windows else "weak", "vs_baseline": None, "dtype": "u32", "data": "synthetic",
             "config": {"workload": f"2^{a.logn}-point {a.curve.capitalize()} MSM per GPU, {a.scalars} 255-bit scalars, "
-                                   f"resident key, device-resident scalars (BASELINE.json configs[1]); a step = a batch of {MPS * B} such MSMs",
+                                   f"resident key, device-resident scalars (BASELINE.json configs[1]); a step = a batch of {MPS * B} such MSMs; `value` is the "
+                                   f"FIXED-KEY figure (commitment keys are fixed for a proof: the key's {plan['tables']} pre-shifted tables are built once, "
+                                   f"key_build_ms, outside the timed region); the variable-base figure on the same inputs is config.plain_key",
+                       "library": library, "key_build_ms": key_build_ms, "plain_key": plain_key,
                        "scalars": "device-resident (generated on the GPU before the timed region; no PCIe traffic inside it)",
                        "host_scalars_ms_per_msm": host_ms,
                        "host_scalars_pageable_ms_per_msm": host_pageable,
@@ -1035,6 +1059,46 @@ def main():
             ctx0.sync()
         s1 = ctx0.timing_stats(reset=True)
         single = {"kernel_ms": s1["accumulate_ms"] / max(s1["calls"], 1), "msm_ms": s1["total_ms"] / max(s1["calls"], 1)}
+        # (1b) the VARIABLE-BASE figure: the same points and scalars on a key with NO precomputed tables (bucket_groups = 0:
+        #      one bucket set per window, nothing but the imported points resident) -- pasta-msm's contract, and what the zero-patch drop-in gets
+        #      for bases it sees once (the IPA's folded generators, framework.rs:695-698).  One MSM in flight, then `streams` in flight.
+        try:
+            torch.cuda.synchronize()
+            t_pk = time.perf_counter()
+            pk0 = msm.MsmContext(a.curve, bases, n, bucket_groups=0)
+            plain_build_ms = (time.perf_counter() - t_pk) * 1e3
+            pks = [pk0] + [pk0.clone() for _ in range(nctx - 1)]
+            pres = [torch.zeros(96, dtype=torch.uint8, device=dev) for _ in pks]
+            for j, c in enumerate(pks):                       # warm-up: workspaces
+                c.msm(scalars, n, out=pres[j].data_ptr())
+                c.sync()
+            t_pk = time.perf_counter()
+            for _ in range(reps):
+                pk0.msm(scalars, n, out=pres[0].data_ptr())
+                pk0.sync()
+            plain_one_ms = (time.perf_counter() - t_pk) / reps * 1e3
+            kk = max(12, min(60, a.steps * MPS))
+            t_pk = time.perf_counter()
+            for i in range(kk):
+                pks[i % nctx].msm(scalars, n, out=pres[i % nctx].data_ptr())
+            for c in pks:
+                c.sync()
+            plain_flight_ms = (time.perf_counter() - t_pk) / kk * 1e3
+            pplan = pk0.plan()
+            same = a.no_check or msm.compress(a.curve, pres[0].cpu().numpy().view(np.uint64)) == msm.compress(a.curve, final_result[:96].view(np.uint64))
+            plain_key = {"ms_per_msm": plain_flight_ms, "pairs_per_s": n / (plain_flight_ms * 1e-3), "one_in_flight_ms_per_msm": plain_one_ms,
+                         "in_flight": nctx, "window_bits": pplan["window_bits"], "windows": pplan["windows"], "tables": pplan["tables"],
+                         "key_build_ms": plain_build_ms, "check": "skipped" if a.no_check else ("same-point-as-the-fixed-key-MSM" if same else "MISMATCH"),
+                         "note": "no precompute: the key is the imported points only (64 B per point resident); device-resident scalars and result, like `value`"}
+            if not same:
+                raise RuntimeError("plain-key MSM differs from the fixed-key MSM")
+            for c in pks:
+                c.close()
+        except Exception as e:
+            print(f"[bench] plain-key leg failed: {e}", file=sys.stderr)
+            plain_key = {"error": str(e)}
+            if "differs" in str(e):
+                raise
         # (2) the same workload with the scalars in pinned HOST memory and the result returned to the host (what Reef's
         #     prover hands over): PCIe-inclusive, the same number of MSMs in flight on their own streams
         try:

@@ -21,6 +21,8 @@
  * (it owns one HIP stream and one workspace); use one ctx (or clone) per concurrent caller.
  *
  * ABI changelog (reef_abi_version()):
+ *   6  round 6: the drop-in symbols build a returning key's resident copy on a builder thread (no call pays for it: reef_key_cache_wait,
+ *      reef_key_cache_stats.spares in place of .reserved); REEF_SC_FENCE defaults to the release-ordered ticket.
  *   5  round 5: device groups (reef_msm_group_*: one MSM split by window or by points, or the rows of a Hyrax commitment dealt out
  *      whole, over several GPUs of ONE process, the partial sums exchanged inside the library: peer copies, host slots, or a
  *      single-process RCCL communicator loaded at run time); reef_merkle_commit_devices (the Merkle tree in blocks over several GPUs); reef_get_device;
@@ -37,7 +39,7 @@
  */
 #ifndef REEF_MSM_H
 #define REEF_MSM_H
-#define REEF_ABI_VERSION 5
+#define REEF_ABI_VERSION 6
 
 #include <stdbool.h>
 #include <stddef.h>
@@ -73,8 +75,11 @@ typedef enum {
  * ------------------------------------------------------------------------------------------- */
 /* (A key that keeps coming back is nominated by non-cryptographic hashes of its bytes, CONFIRMED byte for byte
  * against a retained HOST copy while the GPU already works on the nominated key (helper threads share the comparison of
- * keys above 4 MiB), and, from its third call in the process on, served from a resident pre-shifted copy; a hash collision
- * therefore costs time, never a wrong result, and nothing the caller can observe is retained.  The table of resident keys is
+ * keys above 4 MiB), and served from a resident pre-shifted copy as soon as one exists; a hash collision
+ * therefore costs time, never a wrong result, and nothing the caller can observe is retained.  The resident copy is built OFF the
+ * caller's thread: the call that brings a key's second appearance is served like the first, keeps a copy of the key's bytes and
+ * returns; one builder thread of the process uploads the copy, builds the tables and prepares a ready context for the first call
+ * that finds the key published (typically the third or fourth).  A caller never waits for the builder.  The table of resident keys is
  * one per process (at most 16 keys, REEF_MSM_KEY_CACHE_MB of device memory, default 16384, and REEF_MSM_KEY_HOST_MB of host
  * memory, default 4096; a key stays charged while any thread's context is still attached to it): the key is built once, whichever threads call --
  * nova-snark reaches these symbols from the prover thread and from rayon workers, src/backend/framework.rs:110,
@@ -86,12 +91,15 @@ void mult_pippenger_vesta(reef_jacobian *out, const reef_affine *points, size_t 
                           const reef_fe *scalars, bool is_mont);
 /* What the drop-in symbols' process-wide key table holds (tests, diagnostics): entries nominated, keys with a resident copy,
  * device bytes charged to the budget, and counters since the process started -- resident copies built, calls served from
- * one, per-thread clones made, speculative calls whose bytes turned out to be another key's (served again on the plain path).  reef_key_cache_clear drops every entry (threads let go of their clones at their next call). */
+ * one, per-thread contexts made by the calling threads themselves, speculative calls whose bytes turned out to be another key's (served again on the plain path), ready contexts the builder thread prepared.  reef_key_cache_clear drops every entry (threads let go of their clones at their next call). */
 typedef struct {
-    uint64_t entries, resident_keys, resident_bytes, builds, hits, clones, misspeculated, reserved;
+    uint64_t entries, resident_keys, resident_bytes, builds, hits, clones, misspeculated, spares;
 } reef_key_cache_stats;
 void reef_key_cache_info(reef_key_cache_stats *out);
 void reef_key_cache_clear(void);
+/* Blocks until the builder thread has nothing left to do (tests and timing harnesses that want a deterministic "the key is resident
+ * now"; a prover never needs it). */
+void reef_key_cache_wait(void);
 /* Where the calls served from a resident key spent their time on the HOST, summed over all calling threads since the last reset
  * (nanoseconds; diagnostics: tools/seam_bench): nominating the key (sampled hash + table lookup), enqueueing the MSM (includes the
  * staging of the caller's pageable scalars), confirming the caller's bytes (memcmp against the retained copy, beside the GPU), and

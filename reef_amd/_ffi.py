@@ -1,7 +1,9 @@
 """ctypes binding of libreef_msm.so (the C ABI declared in include/reef_msm.h).
 
-The library is built in-tree (reef_amd/_lib/libreef_msm.so) by `build()`; nothing here falls
-back to a CPU implementation: if the shared object is missing, loading raises.
+The library is built in-tree by `build()`; nothing here falls back to a CPU implementation: if the shared object is
+missing, loading raises.  Two builds of the same sources exist (csrc/Makefile): reef_amd/_lib/libreef_msm.so is the
+RELEASE build -- what load() binds, what bench.py measures, what the GPU suite tests -- and libreef_msm_exp.so carries
+the A/B switches of common.h (load_experiment(): the few tests that force a code path, and tools/).
 """
 from __future__ import annotations
 
@@ -16,7 +18,8 @@ CSRC = os.path.join(_HERE, "csrc")
 # loading it (torch) gets the same if this module is imported first
 if os.environ.get("REEF_MSM_HW_QUEUES", "") != "0":
     os.environ.setdefault("GPU_MAX_HW_QUEUES", os.environ.get("REEF_MSM_HW_QUEUES") or "8")
-LIB_PATH = os.environ.get("REEF_MSM_LIB") or os.path.join(_HERE, "_lib", "libreef_msm.so")   # REEF_MSM_LIB: another build of the same library (experiments)
+LIB_PATH = os.environ.get("REEF_MSM_LIB") or os.path.join(_HERE, "_lib", "libreef_msm.so")   # REEF_MSM_LIB: another build of the same library (tools/: the experiment build)
+EXPERIMENT_LIB_PATH = os.path.join(_HERE, "_lib", "libreef_msm_exp.so")
 HEADER = os.path.join(os.path.dirname(_HERE), "include", "reef_msm.h")
 
 REEF_HOST, REEF_DEVICE = 0, 1
@@ -57,34 +60,33 @@ class KeyCacheTiming(ctypes.Structure):
 
 
 class KeyCacheStats(ctypes.Structure):
-    _fields_ = [(n, c_uint64) for n in ("entries", "resident_keys", "resident_bytes", "builds", "hits", "clones", "misspeculated", "reserved")]
+    _fields_ = [(n, c_uint64) for n in ("entries", "resident_keys", "resident_bytes", "builds", "hits", "clones", "misspeculated", "spares")]
 
 
-ABI_VERSION = 5     # REEF_ABI_VERSION of include/reef_msm.h this binding was written against
+ABI_VERSION = 6     # REEF_ABI_VERSION of include/reef_msm.h this binding was written against
 
 
-def build(force: bool = False, jobs: int = 3) -> str:
-    """Compile every HIP source for gfx950 (hipcc cross-compiles without a GPU)."""
+def build(force: bool = False, jobs: int = 4) -> str:
+    """Compile every HIP source for gfx950, both builds (hipcc cross-compiles without a GPU)."""
     cmd = ["make", "-C", CSRC, f"-j{jobs}"]
     if force:
         cmd.append("-B")
-    subprocess.check_call(cmd, stdout=subprocess.DEVNULL)
-    if not os.path.exists(LIB_PATH):
-        raise RuntimeError("build finished but %s is missing" % LIB_PATH)
+    subprocess.check_call(cmd, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    for path in (os.path.join(_HERE, "_lib", "libreef_msm.so"), EXPERIMENT_LIB_PATH):
+        if not os.path.exists(path):
+            raise RuntimeError("build finished but %s is missing" % path)
     return LIB_PATH
 
 
 _lib = None
+_exp_lib = None
 
 
-def load() -> ctypes.CDLL:
-    global _lib
-    if _lib is not None:
-        return _lib
-    if not os.path.exists(LIB_PATH):
-        raise RuntimeError(f"{LIB_PATH} not built: run `python -c 'import __graft_entry__ as g; g.build()'` "
+def _bind(path: str) -> ctypes.CDLL:
+    if not os.path.exists(path):
+        raise RuntimeError(f"{path} not built: run `python -c 'import __graft_entry__ as g; g.build()'` "
                            "(there is no CPU fallback for the MSM path)")
-    lib = ctypes.CDLL(LIB_PATH)
+    lib = ctypes.CDLL(path)
     vp = c_void_p
     sig = {
         "mult_pippenger_pallas": (None, [vp, vp, c_size_t, vp, c_bool]),
@@ -119,6 +121,7 @@ def load() -> ctypes.CDLL:
         "reef_abi_version": (c_uint32, []),
         "reef_key_cache_info": (None, [POINTER(KeyCacheStats)]),
         "reef_key_cache_clear": (None, []),
+        "reef_key_cache_wait": (None, []),
         "reef_key_cache_timing_get": (None, [POINTER(KeyCacheTiming), c_int]),
         "reef_runtime_init": (c_int, [POINTER(RuntimeOpts), POINTER(RuntimeInfo)]),
         "reef_msm_ctx_last_timing": (c_int, [vp, POINTER(c_float), POINTER(c_float)]),
@@ -161,9 +164,28 @@ def load() -> ctypes.CDLL:
         fn.restype = res
         fn.argtypes = args
     if lib.reef_abi_version() != ABI_VERSION:
-        raise RuntimeError(f"{LIB_PATH} has ABI version {lib.reef_abi_version()}, this binding expects {ABI_VERSION}: rebuild")
-    _lib = lib
+        raise RuntimeError(f"{path} has ABI version {lib.reef_abi_version()}, this binding expects {ABI_VERSION}: rebuild")
     return lib
+
+
+def load() -> ctypes.CDLL:
+    """The product library (the release build unless REEF_MSM_LIB names another)."""
+    global _lib
+    if _lib is None:
+        _lib = _bind(LIB_PATH)
+    return _lib
+
+
+def load_experiment() -> ctypes.CDLL:
+    """The +experiment build of the same sources, beside the product library in the same process (its own streams and caches)."""
+    global _exp_lib
+    if _exp_lib is None:
+        _exp_lib = _bind(EXPERIMENT_LIB_PATH)
+    return _exp_lib
+
+
+def is_release(lib=None) -> bool:
+    return b"+experiment" not in (lib or load()).reef_version()
 
 
 def check(status: int) -> None:

@@ -131,9 +131,9 @@ extern "C" {
 const char *reef_last_error(void) { return g_err; }
 const char *reef_version(void) {
 #ifdef REEF_EXPERIMENT
-    return "reef_msm 0.5 (gfx950; +experiment: the A/B switches of common.h are compiled in)";
+    return "reef_msm 0.6 (gfx950; +experiment: the A/B switches of common.h are compiled in)";
 #else
-    return "reef_msm 0.5 (gfx950; release)";
+    return "reef_msm 0.6 (gfx950; release)";
 #endif
 }
 uint32_t reef_abi_version(void) { return REEF_ABI_VERSION; }
@@ -464,13 +464,8 @@ reef_status reef_merkle_commit_devices(int curve, const reef_poseidon_params *pa
         const uint64_t S = 1ull << L;
         const size_t nb = (size_t)((size[0] + S - 1) / S);
         if (blocks_out) *blocks_out = (uint32_t)nb;
-        struct DeviceScope {
-            int prev = -1;
-            explicit DeviceScope(int d) { (void)hipGetDevice(&prev); (void)hipSetDevice(d); }
-            ~DeviceScope() { if (prev >= 0) (void)hipSetDevice(prev); }
-        };
         if (nb == 1) {
-            DeviceScope ds(devices[0]);
+            REEF_ON_DEVICE(devices[0]);
             return v->merkle_commit(params, doc, n, REEF_HOST, is_mont, tree_out, REEF_HOST, root_out, nullptr);
         }
         std::vector<reef_fe> roots(nb);
@@ -479,7 +474,8 @@ reef_status reef_merkle_commit_devices(int curve, const reef_poseidon_params *pa
         std::vector<std::thread> th;
         for (size_t b = 0; b < nb; ++b)
             th.emplace_back([&, b] {
-                DeviceScope ds(devices[b]);
+                DeviceGuard ds(devices[b]);
+                if (!ds.ok) { set_error("cannot make device %d current: %s", devices[b], hipGetErrorString(ds.err)); st[b] = REEF_ERR_HIP; msg[b] = reef_last_error(); return; }
                 MerkleSlice sl;
                 sl.index_base = 2 * b * S;
                 sl.levels = L;
@@ -511,7 +507,7 @@ reef_status reef_merkle_commit_devices(int curve, const reef_poseidon_params *pa
         top.level_out = dst.data();
         reef_fe root;
         top.top_out = &root;
-        DeviceScope ds(devices[0]);
+        REEF_ON_DEVICE(devices[0]);
         REEF_TRY(v->merkle_commit(params, nullptr, 0, REEF_HOST, is_mont, nullptr, REEF_HOST, nullptr, &top));
         if (root_out) *root_out = root;
         return REEF_OK;
@@ -531,27 +527,36 @@ void reef_shake256(const uint8_t *in, size_t in_len, uint8_t *out, size_t out_le
 // The bases are read on every call, as the reference semantics (nothing retained that the caller can observe) require.
 namespace {
 // A commitment key that keeps coming back (Reef commits to the same generators in every folding step,
-// src/backend/framework.rs:297-303) is recognised by its bytes; from its third appearance on -- in the PROCESS, whichever
-// threads made the calls -- the call runs on a resident pre-shifted copy (import, the plain-key pipeline and the host-side
-// window combine are skipped).  Keys seen once -- the folded generators of an IPA round -- never get a resident copy.
-// REEF_MSM_KEY_CACHE=0 turns it off.
+// src/backend/framework.rs:297-303) is recognised by its bytes; once a resident pre-shifted copy of it exists the call runs on that
+// copy (import, the plain-key pipeline and the host-side window combine are skipped).  Keys seen once -- the folded generators of an
+// IPA round -- never get a resident copy.  REEF_MSM_KEY_CACHE=0 turns it off.
 //
 // Hashes only NOMINATE an entry; a hit is CONFIRMED by comparing every byte the caller passed with the copy retained next to
 // the resident key, so a collision costs time, never a wrong commitment.  The confirmation is free: the caller's thread enqueues
 // the MSM on the nominated key FIRST (speculation) and compares the bytes while the GPU works -- always on the HOST, against a host
-// copy (round 5: no base crosses PCIe on a hit, whatever the key's size; round 4 uploaded keys above 2^17 points to compare them
-// on the device, 1.2 ms of a 3.6 ms call at 2^20 points).  Keys of more than 4 MiB are compared in 1 MiB pieces by the caller and
-// a few helper threads of the process (REEF_MSM_CMP_THREADS, default up to 8: 64 MiB in ~1 ms, beside the scalars' upload and the
-// MSM).  The result is taken only if every byte was equal; otherwise the call is served again on the plain path.
+// copy (round 5: no base crosses PCIe on a hit, whatever the key's size).  Keys of more than 4 MiB are compared in 1 MiB pieces by
+// the caller and a few helper threads of the process (REEF_MSM_CMP_THREADS, default up to 8: 64 MiB in ~1 ms, beside the scalars'
+// upload and the MSM).  The result is taken only if every byte was equal; otherwise the call is served again on the plain path.
+//
+// Round 6 -- NOTHING of a key's warm-up runs on the caller's critical path any more (the call that brought a key's second
+// appearance built the resident copy synchronously, 10-49 ms, and the third paid a context of the thread's own, up to 8 ms; a Reef proof
+// folds 1-6 times, so the warm-up WAS the cost).  The call that brings the second appearance is served on the plain path like the first,
+// keeps a copy of the key's bytes (a memcpy; pieces shared with the helper threads above 4 MiB) and returns; ONE builder thread of the
+// process (Builder, below) uploads that copy, builds the pre-shifted tables -- on a stream the callers already use: creating one would stall them (common.h) -- and, before it publishes the key,
+// prepares a spare context whose workspace has already served a (zero-scalar) MSM of the key's length, with its host-mapped landing zone.
+// The first call that finds the key published takes that spare instead of creating a context.  Until then calls keep to the plain path:
+// a caller never waits for the builder thread (its kernels are ordered among the caller's own on the shared stream: one call waits the 1-2 ms of
+// GPU time the tables take).  The builder also destroys the contexts threads let go of.
 //
 // The table of resident keys is ONE per process (nova-snark reaches this symbol from the prover thread and from rayon workers,
-// src/backend/framework.rs:110,668,695): a key is built once, by the thread that brings its second appearance, and every caller
-// thread serves it through a context of its own attached to the key of the moment (reef_msm_ctx_attach: O(1)).  The table lock is
-// held for lookups only, NEVER across HIP work or a destructor that does HIP work: entries that leave the table are destroyed
-// after the lock is released, and an entry lives on -- charged to the budget -- until the last thread whose context is
-// attached to it has moved on or ended.  Device memory is charged to one budget (REEF_MSM_KEY_CACHE_MB, default 16384), the host
-// copies to another (REEF_MSM_KEY_HOST_MB, default 4096); an allocation failure anywhere on this path empties the table and the
-// thread's contexts and retries once on the plain, uncached path before the symbol gives up.
+// src/backend/framework.rs:110,668,695): a key is built once, and every caller thread serves it through a context of its own attached
+// to the key of the moment (reef_msm_ctx_attach: O(1)).  The table lock is held for lookups only, NEVER across HIP work or a destructor
+// that does HIP work: entries that leave the table are destroyed after the lock is released, and an entry lives on --
+// charged to the budget -- until the last thread whose context is attached to it has moved on or ended.  Device memory is charged to one
+// budget (REEF_MSM_KEY_CACHE_MB, default 16384), the host copies to another (REEF_MSM_KEY_HOST_MB, default 4096), both RESERVED
+// atomically before anything is allocated; a key that finds a budget full goes back to "nominated" and is tried again when it
+// returns.  An allocation failure anywhere on this path empties the table, tells every thread to let go of its attachment at its next
+// call (an epoch), and retries once on the plain, uncached path before the symbol gives up.
 struct SharedKey {
     int curve = 0, device = 0;
     uint64_t hs = 0;                   // hash of n and 64 sampled points: nominates on the fast path
@@ -566,7 +571,8 @@ struct SharedKey {
     ~SharedKey();
 };
 std::atomic<size_t> g_cache_bytes{0}, g_host_bytes{0};
-std::atomic<uint64_t> g_cache_builds{0}, g_cache_hits{0}, g_cache_clones{0}, g_cache_misspeculated{0};
+std::atomic<uint64_t> g_cache_builds{0}, g_cache_hits{0}, g_cache_clones{0}, g_cache_misspeculated{0}, g_cache_spares{0};
+std::atomic<uint64_t> g_cache_epoch{0};            // bumped when the table is emptied: threads drop their attachments at their next call
 std::atomic<uint64_t> g_seam_calls{0}, g_seam_nominate_ns{0}, g_seam_enqueue_ns{0}, g_seam_confirm_ns{0}, g_seam_wait_ns{0};
 static inline uint64_t now_ns() { return (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 // Runs on whichever thread drops the last reference -- never under the table lock (the table hands evicted entries to its caller).
@@ -583,12 +589,20 @@ static size_t env_mb(const char *name, unsigned long long dflt) {
 }
 static size_t cache_budget() { static const size_t b = env_mb("REEF_MSM_KEY_CACHE_MB", 16384); return b; }
 static size_t host_budget() { static const size_t b = env_mb("REEF_MSM_KEY_HOST_MB", 4096); return b; }
-constexpr size_t KEY_CACHE_MIN_POINTS = 1024, KEY_TABLE_ENTRIES = 16;
+// `bytes` of a budget, or nothing: one fetch_add, rolled back when it overshoots (load-then-add let two builders both pass)
+static bool reserve_bytes(std::atomic<size_t> &used, size_t bytes, size_t budget) {
+    if (used.fetch_add(bytes) + bytes <= budget) return true;
+    used.fetch_sub(bytes);
+    return false;
+}
+constexpr size_t KEY_CACHE_MIN_POINTS = 1024, KEY_TABLE_ENTRIES = 16, BG_STREAM_MIN_POINTS = (size_t)1 << 17;
 constexpr size_t CMP_PIECE = (size_t)1 << 20, CMP_PARALLEL_MIN = (size_t)4 << 20;
 
-// ---- the byte comparison of a large key, in pieces, by the caller and the process's helper threads
+// ---- the bytes of a large key, in pieces, by the caller and the process's helper threads: compared with the retained copy (dst == NULL)
+// or copied into a new one (dst != NULL)
 struct CompareJob {
     const char *a = nullptr, *b = nullptr;
+    char *dst = nullptr;
     size_t bytes = 0, pieces = 0;
     std::atomic<size_t> next{0}, done{0};
     std::atomic<int> differ{0};
@@ -597,7 +611,8 @@ struct CompareJob {
             const size_t i = next.fetch_add(1, std::memory_order_relaxed);
             if (i >= pieces) return;                   // nothing of a / b is touched beyond this point: the caller may be gone
             const size_t off = i * CMP_PIECE, len = std::min(CMP_PIECE, bytes - off);
-            if (!differ.load(std::memory_order_relaxed) && memcmp(a + off, b + off, len) != 0) differ.store(1, std::memory_order_relaxed);
+            if (dst) memcpy(dst + off, a + off, len);
+            else if (!differ.load(std::memory_order_relaxed) && memcmp(a + off, b + off, len) != 0) differ.store(1, std::memory_order_relaxed);
             done.fetch_add(1, std::memory_order_release);
         }
     }
@@ -640,21 +655,26 @@ static ComparePool &compare_pool() {
     static ComparePool *p = new ComparePool();
     return *p;
 }
+// a copy of the caller's key bytes that outlives the call (malloc; NULL when the host is out of memory)
+static void *copy_key_bytes(const reef_affine *points, size_t bytes) {
+    void *copy = malloc(bytes);
+    if (!copy) return nullptr;
+    if (bytes < CMP_PARALLEL_MIN) { memcpy(copy, points, bytes); return copy; }
+    auto job = std::make_shared<CompareJob>();
+    job->a = (const char *)points; job->dst = (char *)copy; job->bytes = bytes; job->pieces = (bytes + CMP_PIECE - 1) / CMP_PIECE;
+    compare_pool().help(job);
+    job->work();
+    while (!job->finished()) std::this_thread::yield();
+    return copy;
+}
 
 struct KeyTable {
     std::mutex mu;
     std::vector<std::shared_ptr<SharedKey>> keys;
     std::atomic<uint64_t> tick{0};
     // every entry leaves the table; the entries are destroyed AFTER the lock has been released (their destructors wait for and
-    // free device memory), and a key lives on until the last thread attached to it has let go
-    void clear() {
-        std::vector<std::shared_ptr<SharedKey>> gone;
-        {
-            std::lock_guard<std::mutex> lk(mu);
-            for (auto &k : keys) k->state.store(3);
-            gone.swap(keys);
-        }
-    }
+    // free device memory), and a key lives on until the last thread attached to it has let go -- which the epoch asks of every thread
+    void clear();
 };
 static KeyTable &key_table() {
     static KeyTable *t = new KeyTable();            // never destroyed: static destructors run after HIP may be gone
@@ -689,16 +709,228 @@ static void full_hash(const reef_affine *p, size_t n, uint64_t out[2]) {
     out[0] = hmix(a[0]) ^ hmix(a[1] + 1) ^ hmix(a[2] + 2) ^ hmix(a[3] + 3);
     out[1] = hmix(b[0]) ^ hmix(b[1] + 1) ^ hmix(b[2] + 2) ^ hmix(b[3] + 3) ^ nw;
 }
+
+// A context of the resident path with everything its first call would otherwise have to create: its own workspace, already sized by an
+// MSM of n_warm points, and the host-mapped landing zone the speculative result goes to.
+struct ReadyCtx {
+    reef_msm_ctx *ctx = nullptr;
+    reef_jacobian *pinned = nullptr;
+    int device = -1;
+    size_t n_warm = 0;
+    void destroy() {                                   // HIP work: on the builder thread, or where nobody is waiting
+        reef_msm_ctx_destroy(ctx);
+        if (pinned) (void)hipHostFree(pinned);
+        ctx = nullptr; pinned = nullptr; device = -1; n_warm = 0;
+    }
+};
+static reef_status ready_ctx_make(ReadyCtx *r, reef_msm_ctx *master, int device, size_t n_warm) {
+    r->device = device;
+    {
+        PoolNoGrowth ng;
+        REEF_TRY(reef_msm_ctx_clone(&r->ctx, master));
+    }
+    if (hipHostMalloc((void **)&r->pinned, 128, hipHostMallocDefault) != hipSuccess) {
+        (void)hipGetLastError();
+        r->pinned = nullptr;
+        set_error("hipHostMalloc failed");
+        return REEF_ERR_OOM;
+    }
+    if (n_warm) {                                      // size the workspace: one MSM of the key's length with all-zero scalars
+        void *zeros = calloc(n_warm, sizeof(reef_fe));
+        if (!zeros) { set_error("host memory exhausted"); return REEF_ERR_OOM; }
+        reef_status st = reef_msm(r->ctx, (const reef_fe *)zeros, n_warm, REEF_HOST, true, r->pinned, REEF_DEVICE);
+        if (st == REEF_OK) st = reef_msm_ctx_sync(r->ctx);
+        free(zeros);
+        REEF_TRY(st);
+        r->n_warm = n_warm;
+    }
+    return REEF_OK;
+}
+
+// ONE helper thread per process, started by the first call that has work for it.  Jobs: make sure the pool has streams to hand out (PREPARE),
+// build a key's resident copy and a spare context for it (BUILD), destroy a context a thread let go of (RETIRE).  Callers only ever push
+// and take; they never wait for a job.  At process exit the atexit hook below lets the job in flight finish and drops the rest -- no HIP
+// call of this thread may overlap the runtime's teardown.
+struct Builder {
+    enum Kind { PREPARE, BUILD, RETIRE };
+    struct Job {
+        Kind kind = PREPARE;
+        int device = 0;
+        std::shared_ptr<SharedKey> key;
+        void *copy = nullptr;
+        ReadyCtx retire;
+    };
+    std::mutex mu;
+    std::condition_variable cv, idle_cv;
+    std::deque<Job> q;
+    bool started = false, busy = false;
+    std::vector<ReadyCtx> spares[2];                   // per curve, under mu: at most one per device
+    std::atomic<uint64_t> jobs_done{0};
+
+    void push(Job &&j) {
+        std::lock_guard<std::mutex> lk(mu);
+        if (g_process_exiting.load()) { drop(j); return; }
+        if (!started) {
+            started = true;
+            atexit([] { builder_instance().quiesce(); });   // registered after HIP's own: runs before the runtime goes away
+            std::thread([this] { run(); }).detach();
+        }
+        q.push_back(std::move(j));
+        cv.notify_one();
+    }
+    // the spare of (curve, device) if its workspace has served at least n points
+    bool take(int curve, int device, size_t n, ReadyCtx *out) {
+        std::lock_guard<std::mutex> lk(mu);
+        auto &v = spares[curve];
+        for (size_t i = 0; i < v.size(); ++i)
+            if (v[i].device == device && v[i].n_warm >= n) {
+                *out = v[i];
+                v.erase(v.begin() + i);
+                return true;
+            }
+        return false;
+    }
+    // every spare leaves (the table was emptied: their clones hold references on the keys' tables); destroyed by the caller
+    std::vector<ReadyCtx> take_all() {
+        std::lock_guard<std::mutex> lk(mu);
+        std::vector<ReadyCtx> all;
+        for (auto &v : spares) { all.insert(all.end(), v.begin(), v.end()); v.clear(); }
+        return all;
+    }
+    void wait_idle() {                                 // tests / diagnostics (reef_key_cache_info never waits)
+        std::unique_lock<std::mutex> lk(mu);
+        idle_cv.wait(lk, [&] { return q.empty() && !busy; });
+    }
+    static Builder &builder_instance();
+
+  private:
+    static void drop(Job &j) {                         // a job that will never run: host memory only (the process is going away)
+        free(j.copy);
+        j.copy = nullptr;
+        if (j.kind == BUILD && j.key) {
+            g_cache_bytes -= j.key->charged; g_host_bytes -= j.key->host_charged;
+            j.key->charged = j.key->host_charged = 0;
+            int expect = 1;
+            j.key->state.compare_exchange_strong(expect, 0);
+        }
+    }
+    void quiesce() {
+        g_process_exiting.store(true);
+        std::unique_lock<std::mutex> lk(mu);
+        for (auto &j : q) drop(j);
+        q.clear();
+        idle_cv.wait(lk, [&] { return !busy; });
+    }
+    void run() {
+        t_pool_no_growth = true;                       // this thread never creates a stream while one exists: its work is ordered on a stream the callers use (common.h)
+        for (;;) {
+            Job j;
+            {
+                std::unique_lock<std::mutex> lk(mu);
+                cv.wait(lk, [&] { return !q.empty(); });
+                if (g_process_exiting.load()) { for (auto &x : q) drop(x); q.clear(); continue; }
+                j = std::move(q.front());
+                q.pop_front();
+                busy = true;
+            }
+            static const bool log_jobs = [] { const char *l = getenv("REEF_MSM_LOG"); return l && atoi(l) >= 2; }();
+            const uint64_t tj = now_ns();
+            const Kind kind = j.kind;
+            const size_t npts = j.key ? j.key->n : 0;
+            try {
+                execute(j);
+            } catch (...) {                            // bad_alloc and friends: the key stays on the plain path
+                if (j.kind == BUILD) fail_build(j, 4);
+            }
+            jobs_done += 1;
+            if (log_jobs)
+                fprintf(stderr, "libreef_msm: builder job %s (%zu points) took %.3f ms, ended at %.3f ms\n", kind == PREPARE ? "PREPARE" : kind == BUILD ? "BUILD" : "RETIRE", npts,
+                        (now_ns() - tj) * 1e-6, (now_ns() % 100000000000ull) * 1e-6);
+            {
+                std::lock_guard<std::mutex> lk(mu);
+                busy = false;
+            }
+            idle_cv.notify_all();
+        }
+    }
+    static void fail_build(Job &j, int state) {
+        free(j.copy);
+        j.copy = nullptr;
+        g_cache_bytes -= j.key->charged; g_host_bytes -= j.key->host_charged;
+        j.key->charged = j.key->host_charged = 0;
+        int expect = 1;                                // an entry evicted meanwhile (state 3) stays evicted
+        j.key->state.compare_exchange_strong(expect, state, std::memory_order_release);
+    }
+    void execute(Job &j) {
+        if (j.kind == RETIRE) { j.retire.destroy(); return; }
+        DeviceGuard dg(j.device);
+        if (!dg.ok) { if (j.kind == BUILD) fail_build(j, 4); return; }
+        if (j.kind == PREPARE) return;                 // (kept for embedders' diagnostics; nothing to prepare since the pool no longer grows here)
+        SharedKey &k = *j.key;
+        // a long build gets (once per process and device) a stream of this thread's own: on a caller's stream its kernels would keep that
+        // caller's next call waiting for the whole build; short ones are not worth a stream creation (common.h)
+        if (k.n >= BG_STREAM_MIN_POINTS) (void)stream_pool().ensure_background_stream(k.device);
+        reef_msm_opts o = {};
+        o.bucket_groups = 1;
+        o.byte_tables = 2;                             // never for a key the caller did not create: 256 KiB per point would dwarf the budget
+        o.device = k.device;
+        reef_msm_ctx *master = nullptr;
+        if (reef_msm_ctx_create(&master, k.curve, (const reef_affine *)j.copy, k.n, REEF_HOST, &o) != REEF_OK) { fail_build(j, 4); return; }
+        ReadyCtx spare;
+        if (ready_ctx_make(&spare, master, k.device, k.n) != REEF_OK) spare.destroy();      // never fatal: the first caller makes its own
+        k.host_copy = j.copy;
+        k.master = master;
+        j.copy = nullptr;
+        g_cache_builds += 1;
+        ReadyCtx old;
+        if (spare.ctx) {                               // BEFORE the key is published: whoever sees state 2 finds the spare
+            std::lock_guard<std::mutex> lk(mu);
+            auto &v = spares[k.curve];
+            for (size_t i = 0; i < v.size(); ++i)
+                if (v[i].device == k.device) { old = v[i]; v.erase(v.begin() + i); break; }
+            v.push_back(spare);
+            g_cache_spares += 1;
+        }
+        int expect = 1;                                // an entry evicted meanwhile (state 3) stays evicted; its destructor frees what was built
+        if (!k.state.compare_exchange_strong(expect, 2, std::memory_order_release) && spare.ctx) {
+            bool mine = false;                         // nobody will ask for this key: its spare must not keep the tables alive
+            {
+                std::lock_guard<std::mutex> lk(mu);
+                auto &v = spares[k.curve];
+                for (size_t i = 0; i < v.size(); ++i)
+                    if (v[i].ctx == spare.ctx) { v.erase(v.begin() + i); mine = true; break; }
+            }
+            if (mine) spare.destroy();
+        }
+        if (old.ctx) old.destroy();                    // the previous key's spare nobody took
+    }
+};
+Builder &Builder::builder_instance() {
+    static Builder *b = new Builder();                 // never destroyed
+    return *b;
+}
+static Builder &builder() { return Builder::builder_instance(); }
+
+void KeyTable::clear() {
+    std::vector<std::shared_ptr<SharedKey>> gone;
+    {
+        std::lock_guard<std::mutex> lk(mu);
+        for (auto &k : keys) k->state.store(3);
+        gone.swap(keys);
+    }
+    g_cache_epoch += 1;
+    for (auto &r : builder().take_all()) r.destroy();
+}
+
 struct TlsCtx {
     reef_msm_ctx *ctx[2] = {nullptr, nullptr};      // plain path: re-keyed on every call
-    reef_msm_ctx *rctx[2] = {nullptr, nullptr};     // resident path: this thread's stream and workspace, attached to whichever shared key a call nominates
-    std::shared_ptr<SharedKey> attached[2];         // the key rctx is attached to: it (and its share of the budget) lives while any thread's context is on its tables
-    int ctx_dev[2] = {-1, -1}, rctx_dev[2] = {-1, -1};
-    reef_jacobian *pinned = nullptr;                // host-mapped: the speculative result lands here
+    ReadyCtx r[2];                                  // resident path: this thread's stream, workspace and landing zone, attached to whichever shared key a call nominates
+    std::shared_ptr<SharedKey> attached[2];         // the key r[c] is attached to: it (and its share of the budget) lives while any thread's context is on its tables
+    int ctx_dev[2] = {-1, -1};
+    uint64_t epoch = 0;
     void drop_resident() {
         for (int c = 0; c < 2; ++c) {
-            reef_msm_ctx_destroy(rctx[c]);
-            rctx[c] = nullptr;
+            r[c].destroy();
             attached[c].reset();                       // after the context: the key's destructor frees what the context was reading
         }
     }
@@ -706,7 +938,6 @@ struct TlsCtx {
         if (g_process_exiting.load()) return;          // process teardown: never call into HIP (the keys' destructors look at the same flag)
         for (auto *c : ctx) reef_msm_ctx_destroy(c);
         drop_resident();
-        if (pinned) (void)hipHostFree(pinned);
     }
 };
 thread_local TlsCtx g_tls;
@@ -717,6 +948,7 @@ static reef_status pippenger_plain(int curve, reef_jacobian *out, const reef_aff
     REEF_HIP_TRY(hipGetDevice(&dev));
     if (c && g_tls.ctx_dev[curve] != dev) { reef_msm_ctx_destroy(c); c = nullptr; }   // the caller moved to another GPU
     if (!c) {
+        PoolNoGrowth ng;                               // the context takes a stream when it has work; a second stream only when two callers really overlap
         REEF_TRY(reef_msm_ctx_create(&c, curve, points, npoints, REEF_HOST, nullptr));
         g_tls.ctx_dev[curve] = dev;
     } else {
@@ -725,39 +957,32 @@ static reef_status pippenger_plain(int curve, reef_jacobian *out, const reef_aff
     return reef_msm(c, scalars, npoints, REEF_HOST, is_mont, out, REEF_HOST);
 }
 
-// The resident copy of a key whose second appearance this thread brought: the bytes + the pre-shifted tables.  Failure is
-// never fatal -- the key keeps being served on the plain path.
-static void build_resident(const std::shared_ptr<SharedKey> &k, const reef_affine *points) {
+// The call that brought the key's second appearance (state 1 is ours) has been served: reserve the budgets, keep the bytes, hand the
+// build to the builder thread.  Failure is never fatal -- the key keeps being served on the plain path.
+static void schedule_build(const std::shared_ptr<SharedKey> &k, const reef_affine *points) {
     const size_t bytes = k->n * sizeof(reef_affine);
     uint32_t T = 1;
     (void)reef_msm_plan_for(k->n, 0, 1, nullptr, nullptr, nullptr, &T);
     const size_t cost = bytes * (size_t)T;             // T pre-shifted tables
-    int done = 4;
-    if (g_cache_bytes.load() + cost <= cache_budget() && g_host_bytes.load() + bytes <= host_budget()) {
-        reef_msm_opts o = {};
-        o.bucket_groups = 1;
-        o.byte_tables = 2;                             // never for a key the caller did not create: 256 KiB per point would dwarf the budget
-        o.device = k->device;
-        void *copy = malloc(bytes);
-        reef_msm_ctx *master = nullptr;
-        bool ok = copy != nullptr;
-        if (ok) memcpy(copy, points, bytes);
-        ok = ok && reef_msm_ctx_create(&master, k->curve, points, k->n, REEF_HOST, &o) == REEF_OK;
-        if (ok) {
-            k->host_copy = copy;
-            k->master = master;
-            k->charged = cost;
-            k->host_charged = bytes;
-            g_cache_bytes += cost;
-            g_host_bytes += bytes;
-            g_cache_builds += 1;
-            done = 2;
-        } else {
-            free(copy);
+    int back_to = 0;                                   // a full budget: nominated again, tried again when the key returns
+    if (reserve_bytes(g_cache_bytes, cost, cache_budget())) {
+        if (reserve_bytes(g_host_bytes, bytes, host_budget())) {
+            void *copy = copy_key_bytes(points, bytes);
+            if (copy) {
+                k->charged = cost;
+                k->host_charged = bytes;
+                Builder::Job j;
+                j.kind = Builder::BUILD; j.device = k->device; j.key = k; j.copy = copy;
+                builder().push(std::move(j));
+                return;
+            }
+            back_to = 4;                               // the host is out of memory: not worth another try
+            g_host_bytes -= bytes;
         }
+        g_cache_bytes -= cost;
     }
     int expect = 1;                                    // an entry evicted meanwhile (state 3) stays evicted
-    k->state.compare_exchange_strong(expect, done, std::memory_order_release);
+    k->state.compare_exchange_strong(expect, back_to, std::memory_order_release);
 }
 
 // The call on the resident key `k`, speculatively: *same = the caller's bytes are the key's (then *out holds the result).
@@ -765,22 +990,30 @@ static reef_status pippenger_resident(const std::shared_ptr<SharedKey> &k, reef_
                                       const reef_fe *scalars, bool is_mont, bool *same) {
     const size_t bytes = npoints * sizeof(reef_affine);
     const int curve = k->curve;
-    reef_msm_ctx *&c = g_tls.rctx[curve];
-    if (c && g_tls.rctx_dev[curve] != k->device) { reef_msm_ctx_destroy(c); c = nullptr; g_tls.attached[curve].reset(); }
-    if (!c) {
-        REEF_TRY(reef_msm_ctx_clone(&c, k->master));
-        g_tls.rctx_dev[curve] = k->device;
+    ReadyCtx &r = g_tls.r[curve];
+    auto retire = [&] {                                // destroyed by the builder thread, not here
+        Builder::Job j;
+        j.kind = Builder::RETIRE; j.retire = r;
+        r = ReadyCtx();
+        g_tls.attached[curve].reset();                 // (the retired context still holds its reference on the key's tables until it is destroyed)
+        builder().push(std::move(j));
+    };
+    if (r.ctx && r.device != k->device) retire();
+    if (!r.ctx || r.n_warm < npoints) {                // the spare the builder prepared for a key of this size
+        ReadyCtx s;
+        if (builder().take(curve, k->device, npoints, &s)) {
+            if (r.ctx) retire();
+            r = s;
+        }
+    }
+    if (!r.ctx) {                                      // no spare (another thread took it): this thread makes its own
+        const reef_status st = ready_ctx_make(&r, k->master, k->device, 0);
+        if (st != REEF_OK) { r.destroy(); return st; }
         g_cache_clones += 1;
-    } else if (g_tls.attached[curve] != k) {
-        REEF_TRY(reef_msm_ctx_attach(c, k->master));   // O(1): the thread's stream and workspace on another key's tables
     }
+    if (g_tls.attached[curve] != k) REEF_TRY(reef_msm_ctx_attach(r.ctx, k->master));   // O(1): the thread's stream and workspace on another key's tables
     g_tls.attached[curve] = k;                         // the key this thread let go of may end here (its last reference): outside every lock
-    if (!g_tls.pinned && hipHostMalloc((void **)&g_tls.pinned, 128, hipHostMallocDefault) != hipSuccess) {
-        (void)hipGetLastError();
-        g_tls.pinned = nullptr;
-        set_error("hipHostMalloc failed");
-        return REEF_ERR_OOM;
-    }
+    reef_msm_ctx *c = r.ctx;
     const uint64_t t0 = now_ns();
     std::shared_ptr<CompareJob> job;
     if (bytes >= CMP_PARALLEL_MIN) {                   // a large key: the helpers start on it while this thread stages the scalars
@@ -788,7 +1021,7 @@ static reef_status pippenger_resident(const std::shared_ptr<SharedKey> &k, reef_
         job->a = (const char *)points; job->b = (const char *)k->host_copy; job->bytes = bytes; job->pieces = (bytes + CMP_PIECE - 1) / CMP_PIECE;
         compare_pool().help(job);
     }
-    const reef_status issued = reef_msm(c, scalars, npoints, REEF_HOST, is_mont, g_tls.pinned, REEF_DEVICE);   // enqueued; the result goes to host-mapped memory
+    const reef_status issued = reef_msm(c, scalars, npoints, REEF_HOST, is_mont, r.pinned, REEF_DEVICE);   // enqueued; the result goes to host-mapped memory
     const uint64_t t1 = now_ns();
     bool eq;
     if (job) {                                         // the caller's pointers must outlive every piece in flight, whatever `issued` says
@@ -802,10 +1035,11 @@ static reef_status pippenger_resident(const std::shared_ptr<SharedKey> &k, reef_
     REEF_TRY(issued);
     REEF_TRY(reef_msm_ctx_sync(c));
     const uint64_t t3 = now_ns();
+    r.n_warm = std::max(r.n_warm, npoints);
     g_seam_calls += 1; g_seam_enqueue_ns += t1 - t0; g_seam_confirm_ns += t2 - t1; g_seam_wait_ns += t3 - t2;
     *same = eq;
     if (eq) {
-        memcpy(out, g_tls.pinned, sizeof(reef_jacobian));
+        memcpy(out, r.pinned, sizeof(reef_jacobian));
         g_cache_hits += 1;
     } else {
         g_cache_misspeculated += 1;
@@ -817,6 +1051,13 @@ static reef_status pippenger_cached(int curve, reef_jacobian *out, const reef_af
     int dev = 0;
     REEF_HIP_TRY(hipGetDevice(&dev));
     KeyTable &tab = key_table();
+    {
+        const uint64_t ep = g_cache_epoch.load();
+        if (g_tls.epoch != ep) {                       // the table was emptied (reef_key_cache_clear, or another thread's allocation failure)
+            g_tls.drop_resident();
+            g_tls.epoch = ep;
+        }
+    }
     const uint64_t tn = now_ns();
     const uint64_t hs = sampled_hash(points, npoints);
     std::shared_ptr<SharedKey> k;
@@ -837,7 +1078,7 @@ static reef_status pippenger_cached(int curve, reef_jacobian *out, const reef_af
     }
     uint64_t hf[2];
     full_hash(points, npoints, hf);
-    bool builder = false;
+    bool builder_of = false;
     std::shared_ptr<SharedKey> evicted;                // destroyed after the lock below has been released (declared before it)
     {
         std::lock_guard<std::mutex> lk(tab.mu);
@@ -848,7 +1089,7 @@ static reef_status pippenger_cached(int curve, reef_jacobian *out, const reef_af
             k->last_use.store(now);
             k->seen += 1;
             int expect = 0;
-            builder = k->seen >= 2 && k->state.compare_exchange_strong(expect, 1);   // second appearance: worth a resident copy
+            builder_of = k->seen >= 2 && k->state.compare_exchange_strong(expect, 1);   // second appearance: worth a resident copy
         } else {
             if (tab.keys.size() >= KEY_TABLE_ENTRIES) {  // forget the least recently used key; keys seen once (no resident copy) go first
                 size_t lru = tab.keys.size();
@@ -873,16 +1114,22 @@ static reef_status pippenger_cached(int curve, reef_jacobian *out, const reef_af
         }
     }
     evicted.reset();                                   // here: HIP work of the destructor (if this was the last reference) outside the lock
-    if (k && !builder && k->state.load(std::memory_order_acquire) == 2) {   // resident, but not what the samples nominated first
+    if (k && !builder_of && k->state.load(std::memory_order_acquire) == 2) {   // resident, but not what the samples nominated first
         bool same = false;
         REEF_TRY(pippenger_resident(k, out, points, npoints, scalars, is_mont, &same));
         if (same) return REEF_OK;
     }
-    const reef_status st = pippenger_plain(curve, out, points, npoints, scalars, is_mont);
-    if (builder) {
-        if (st == REEF_OK) build_resident(k, points);
+    static const bool log_calls = [] { const char *l = getenv("REEF_MSM_LOG"); return l && atoi(l) >= 2; }();
+    const uint64_t tp0 = log_calls ? now_ns() : 0;
+    const reef_status st = pippenger_plain(curve, out, points, npoints, scalars, is_mont);   // also while the builder is at work on this key
+    const uint64_t tp1 = log_calls ? now_ns() : 0;
+    if (builder_of) {
+        if (st == REEF_OK) schedule_build(k, points);
         else { int expect = 1; k->state.compare_exchange_strong(expect, 0); }
     }
+    if (log_calls)
+        fprintf(stderr, "libreef_msm: plain-path call (%zu points): nominate + hash %.3f ms, plain MSM %.3f ms, hand-over to the builder %.3f ms\n", npoints, (tp0 - tn) * 1e-6,
+                (tp1 - tp0) * 1e-6, (now_ns() - tp1) * 1e-6);
     return st;
 }
 
@@ -892,8 +1139,10 @@ static reef_status pippenger_try(int curve, reef_jacobian *out, const reef_affin
     reef_status st = (!cache_on || npoints < KEY_CACHE_MIN_POINTS) ? pippenger_plain(curve, out, points, npoints, scalars, is_mont)
                                                                      : pippenger_cached(curve, out, points, npoints, scalars, is_mont);
     if (st == REEF_ERR_OOM) {                           // give the cache's memory back and serve the call uncached
-        key_table().clear();
+        builder().wait_idle();                          // a build in flight holds memory too; its key is gone from the table after clear()
+        key_table().clear();                            // every thread lets go of its attachment at its next call (epoch)
         g_tls.drop_resident();
+        g_tls.epoch = g_cache_epoch.load();
         st = pippenger_plain(curve, out, points, npoints, scalars, is_mont);
     }
     return st;
@@ -919,9 +1168,10 @@ void reef_key_cache_info(reef_key_cache_stats *out) {
     out->hits = g_cache_hits.load();
     out->clones = g_cache_clones.load();
     out->misspeculated = g_cache_misspeculated.load();
-    out->reserved = 0;
+    out->spares = g_cache_spares.load();
 }
 void reef_key_cache_clear(void) { key_table().clear(); }
+void reef_key_cache_wait(void) { builder().wait_idle(); }
 void reef_key_cache_timing_get(reef_key_cache_timing *out, int reset) {
     if (out) {
         memset(out, 0, sizeof *out);

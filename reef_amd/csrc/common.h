@@ -3,6 +3,8 @@
 #include <algorithm>
 #include <atomic>
 #include <mutex>
+#include <thread>
+#include <stdio.h>
 #include <stdlib.h>
 #include <vector>
 #include <hip/hip_runtime.h>
@@ -45,6 +47,35 @@ inline const char *exp_env(const char *name) {
 #endif
 }
 
+// Allocations and launches of a context must target the device its key lives on, whatever the calling thread's current device is.  A
+// hipSetDevice that FAILS must not go unnoticed -- the work that follows would silently go to the caller's device: entry points
+// open the scope with REEF_ON_DEVICE and return REEF_ERR_HIP.
+struct DeviceGuard {
+    int prev = -1;
+    bool switched = false, ok = true;
+    hipError_t err = hipSuccess;
+    explicit DeviceGuard(int dev) {
+        err = hipGetDevice(&prev);
+        if (err == hipSuccess && prev != dev) {
+            err = hipSetDevice(dev);
+            switched = err == hipSuccess;
+        }
+        ok = err == hipSuccess;
+        if (!ok) (void)hipGetLastError();
+    }
+    ~DeviceGuard() {
+        if (switched) (void)hipSetDevice(prev);
+    }
+    DeviceGuard(const DeviceGuard &) = delete;
+    DeviceGuard &operator=(const DeviceGuard &) = delete;
+};
+#define REEF_ON_DEVICE(dev)                                                                                   \
+    ::reef::DeviceGuard dg_((dev));                                                                           \
+    if (!dg_.ok) {                                                                                            \
+        ::reef::set_error("cannot make device %d current: %s", (int)(dev), hipGetErrorString(dg_.err));       \
+        return REEF_ERR_HIP;                                                                                  \
+    }
+
 // Grow-only device buffer (steady state performs no allocation).
 // Bumped whenever a workspace buffer is (re)allocated or released: captured hipGraphs hold raw device pointers and are
 // dropped when the generation they were captured under is gone (engine.inc, run_core_graphed).
@@ -79,11 +110,25 @@ struct DevBuf {
 // most REEF_MSM_STREAMS (default 8) streams per device, created one at a time when every existing one has a caller at work, and
 // a context (or a stateless call) takes the stream with the fewest callers AT WORK each time it starts from idle -- all its
 // earlier work has been waited for -- and keeps it until it is idle again.  Sharing a stream only adds ordering, never removes it.
+// hipStreamCreate is the most expensive call the library makes after start-up: 7-9 ms per stream while the runtime still has hardware queues to
+// set up (the first GPU_MAX_HW_QUEUES streams of the process), 2 ms afterwards -- and while it runs, every HIP call of every OTHER thread stalls
+// up to 0.8 ms (reef_amd/csrc/tools/stream_probe.hip, profiles/r06_stream_probe.txt: a 20-launch MSM beside two creations read 15 ms).  So the
+// pool grows only for callers that are really concurrent.  A thread that sets this flag (the drop-in symbols' builder thread, for life; the
+// symbols' own per-thread contexts while they are created: api.cpp) shares the least loaded existing stream instead of creating one.
+inline thread_local bool t_pool_no_growth = false;
+struct PoolNoGrowth {
+    bool prev;
+    PoolNoGrowth() : prev(t_pool_no_growth) { t_pool_no_growth = true; }
+    ~PoolNoGrowth() { t_pool_no_growth = prev; }
+};
 struct PoolStream {
     hipStream_t s = nullptr;
     int device = 0;
     std::atomic<int> active{0};      // callers between their first enqueue and the wait that found them idle again
     std::atomic<int> pins{0};        // contexts whose stream was handed to the caller (reef_msm_ctx_stream): they stay here for life
+    bool bg_only = false;            // created for the no-growth threads alone (ensure_background_stream): callers never take it
+    std::atomic<int> background{0};  // no-growth threads at work here (the drop-in symbols' builder): they share a stream, and a caller that finds only
+                                     // THEM on it shares it too instead of creating the next one (a creation on the caller's thread: 8 ms, measured)
 };
 struct StreamPool {
     std::mutex mu;
@@ -92,64 +137,96 @@ struct StreamPool {
         static const size_t v = [] { const char *e = getenv("REEF_MSM_STREAMS"); const long n = e ? atol(e) : 8; return (size_t)(n < 1 ? 1 : n > 64 ? 64 : n); }();
         return v;
     }
-    // the stream of `device` with the fewest callers at work (counted for the caller from here on: leave() when idle again)
-    reef_status pick(int device, PoolStream **out) {
-        std::lock_guard<std::mutex> lk(mu);
-        PoolStream *best = nullptr;
-        size_t on_device = 0;
-        for (PoolStream *p : streams)
-            if (p->device == device) {
-                ++on_device;
-                if (!best || p->active.load(std::memory_order_relaxed) < best->active.load(std::memory_order_relaxed)) best = p;
+    // A stream is created OUTSIDE the pool lock (hipStreamCreate takes milliseconds while the runtime still has hardware queues to set up, and
+    // since round 6 a helper thread creates contexts beside the callers: api.cpp, Builder): the callers' pick() never waits behind one.
+    static PoolStream *make(int device, hipError_t *err) {
+        PoolStream *p = new PoolStream();
+        p->device = device;
+        *err = hipStreamCreateWithFlags(&p->s, hipStreamNonBlocking);   // the caller's current device is `device` (DeviceGuard)
+        if (*err != hipSuccess) { delete p; (void)hipGetLastError(); return nullptr; }
+        static const bool log = [] { const char *l = getenv("REEF_MSM_LOG"); return l && atoi(l) >= 2; }();
+        if (log) fprintf(stderr, "libreef_msm: stream created on device %d\n", device);
+        return p;
+    }
+    // a stream reserved for a graph capture (engine.inc, run_core_graphed) is nobody else's until the capture has ended
+    static constexpr int RESERVED = 1 << 20;
+    static int load_of(const PoolStream *p, bool for_pin) {
+        const int a = 2 * p->active.load(std::memory_order_relaxed) + p->background.load(std::memory_order_relaxed);
+        return for_pin ? 2000 * p->pins.load(std::memory_order_relaxed) + a : a;
+    }
+    // the stream of `device` with the smallest load (callers at work; for_pin: contexts pinned to it first), a new one while every stream has
+    // work and the pool may grow.  A stream under capture is skipped; when every stream is (REEF_MSM_STREAMS=1 ...) the caller waits for the
+    // capture to end -- it lasts microseconds.
+    reef_status pick_impl(int device, PoolStream **out, bool for_pin) {
+        for (;;) {
+            bool grow = false;
+            {
+                std::lock_guard<std::mutex> lk(mu);
+                PoolStream *best = nullptr;
+                size_t on_device = 0;
+                for (PoolStream *p : streams)
+                    if (p->device == device) {
+                        if (p->bg_only) {                      // the builder's own stream, once it exists: its work goes there and nowhere else
+                            if (t_pool_no_growth && !for_pin) { best = p; break; }
+                            continue;
+                        }
+                        ++on_device;
+                        if (p->active.load(std::memory_order_relaxed) >= RESERVED) continue;
+                        if (!best || load_of(p, for_pin) < load_of(best, for_pin)) best = p;
+                    }
+                grow = !t_pool_no_growth && on_device < limit() && (!best || (for_pin ? load_of(best, true) > 0 : best->active.load(std::memory_order_relaxed) > 0));
+                if (!grow && best) {
+                    count_in(best, for_pin);
+                    *out = best;
+                    return REEF_OK;
+                }
+                if (!grow && on_device == 0) grow = true;     // limit() >= 1: cannot happen, but never spin on an empty pool
             }
-        if (!best || (best->active.load(std::memory_order_relaxed) > 0 && on_device < limit())) {
-            PoolStream *p = new PoolStream();
-            p->device = device;
-            hipError_t e = hipStreamCreateWithFlags(&p->s, hipStreamNonBlocking);   // the caller's current device is `device` (DeviceGuard)
-            if (e != hipSuccess) {
-                delete p;
-                if (!best) { set_error("hipStreamCreate: %s", hipGetErrorString(e)); return REEF_ERR_HIP; }
-                (void)hipGetLastError();
-            } else {
+            if (!grow) { std::this_thread::yield(); continue; }   // every stream is under capture
+            hipError_t e = hipSuccess;
+            PoolStream *p = make(device, &e);
+            std::lock_guard<std::mutex> lk(mu);
+            if (p) {
+                count_in(p, for_pin);
                 streams.push_back(p);
-                best = p;
+                *out = p;
+                return REEF_OK;
             }
+            PoolStream *best = nullptr;                       // no new stream to be had: share the least loaded one
+            for (PoolStream *q : streams)
+                if (q->device == device && !q->bg_only && q->active.load(std::memory_order_relaxed) < RESERVED && (!best || load_of(q, for_pin) < load_of(best, for_pin))) best = q;
+            if (!best) { set_error("hipStreamCreate: %s", hipGetErrorString(e)); return REEF_ERR_HIP; }
+            count_in(best, for_pin);
+            *out = best;
+            return REEF_OK;
         }
-        best->active.fetch_add(1, std::memory_order_relaxed);
-        *out = best;
-        return REEF_OK;
+    }
+    static void count_in(PoolStream *p, bool for_pin) {
+        if (for_pin) p->pins.fetch_add(1, std::memory_order_relaxed);
+        else if (t_pool_no_growth) p->background.fetch_add(1, std::memory_order_relaxed);
+        else p->active.fetch_add(1, std::memory_order_relaxed);
+    }
+    // counted for the caller from here on (*background: as a no-growth thread): leave() with the same flag when idle again
+    reef_status pick(int device, PoolStream **out, bool *background = nullptr) {
+        if (background) *background = t_pool_no_growth;
+        return pick_impl(device, out, false);
     }
     // a stream for a context that will STAY on it (its stream is handed to the caller, e.g. for RCCL ordering): the one with the
     // fewest such contexts, then the fewest callers at work -- three pinned contexts of a bench rank must not share one stream
-    reef_status pick_for_pin(int device, PoolStream **out) {
-        std::lock_guard<std::mutex> lk(mu);
-        PoolStream *best = nullptr;
-        size_t on_device = 0;
-        auto load = [](PoolStream *p) { return 1000 * p->pins.load(std::memory_order_relaxed) + p->active.load(std::memory_order_relaxed); };
-        for (PoolStream *p : streams)
-            if (p->device == device) {
-                ++on_device;
-                if (!best || load(p) < load(best)) best = p;
-            }
-        if (!best || (load(best) > 0 && on_device < limit())) {
-            PoolStream *p = new PoolStream();
-            p->device = device;
-            hipError_t e = hipStreamCreateWithFlags(&p->s, hipStreamNonBlocking);
-            if (e != hipSuccess) {
-                delete p;
-                if (!best) { set_error("hipStreamCreate: %s", hipGetErrorString(e)); return REEF_ERR_HIP; }
-                (void)hipGetLastError();
-            } else {
-                streams.push_back(p);
-                best = p;
-            }
-        }
-        best->pins.fetch_add(1, std::memory_order_relaxed);
-        *out = best;
-        return REEF_OK;
+    reef_status pick_for_pin(int device, PoolStream **out) { return pick_impl(device, out, true); }
+    // Graph capture needs the stream to itself: reserve it iff the caller (counted once in `active`, pinned or not) is its only user -- one
+    // compare-and-swap, so no other caller can slip in between the check and the reservation.
+    bool try_reserve(PoolStream *p, int own_pins) {
+        std::lock_guard<std::mutex> lk(mu);                // picks count themselves in under this lock: none can land between the checks
+        if (p->pins.load(std::memory_order_relaxed) > own_pins || p->background.load(std::memory_order_relaxed) > 0) return false;
+        int expect = 1;
+        return p->active.compare_exchange_strong(expect, 1 + RESERVED, std::memory_order_acq_rel);
     }
-    static void leave(PoolStream *p) {
-        if (p) p->active.fetch_sub(1, std::memory_order_relaxed);
+    static void unreserve(PoolStream *p) { p->active.fetch_sub(RESERVED, std::memory_order_acq_rel); }
+    static void leave(PoolStream *p, bool background = false) {
+        if (!p) return;
+        if (background) p->background.fetch_sub(1, std::memory_order_relaxed);
+        else p->active.fetch_sub(1, std::memory_order_relaxed);
     }
     // Creating a stream is expensive while the runtime still has hardware queues to create (several ms each, measured: the first
     // concurrent use of three contexts read 23 ms instead of 6), so it is done where contexts are CREATED, never in a hot call if
@@ -157,17 +234,42 @@ struct StreamPool {
     std::atomic<int> contexts_alive{0};
     reef_status context_created(int device) {
         const size_t want = std::min<size_t>((size_t)std::max(1, ++contexts_alive), limit());
-        std::lock_guard<std::mutex> lk(mu);
-        size_t on_device = 0;
-        for (PoolStream *p : streams) on_device += p->device == device;
-        for (; on_device < want; ++on_device) {
-            PoolStream *p = new PoolStream();
-            p->device = device;
-            hipError_t e = hipStreamCreateWithFlags(&p->s, hipStreamNonBlocking);
-            if (e != hipSuccess) { delete p; set_error("hipStreamCreate: %s", hipGetErrorString(e)); return REEF_ERR_HIP; }
-            streams.push_back(p);
+        if (t_pool_no_growth) return REEF_OK;              // an internal context of the drop-in symbols: it takes a stream when it has work (pick)
+        return ensure_streams(device, want);
+    }
+    // A stream of `device` that only no-growth threads use, created (by such a thread, outside the lock) the first time its work is long
+    // enough to be worth ~8 ms of creation: ordered on a caller's stream, the table build of a 2^20-point key kept the caller's next call
+    // waiting 20 ms (profiles/r06_seam_first_calls.txt).  Beyond REEF_MSM_STREAMS: it is not the callers'.
+    reef_status ensure_background_stream(int device) {
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            for (PoolStream *p : streams)
+                if (p->device == device && p->bg_only) return REEF_OK;
         }
+        hipError_t e = hipSuccess;
+        PoolStream *p = make(device, &e);
+        if (!p) { set_error("hipStreamCreate: %s", hipGetErrorString(e)); return REEF_ERR_HIP; }
+        p->bg_only = true;
+        std::lock_guard<std::mutex> lk(mu);
+        streams.push_back(p);
         return REEF_OK;
+    }
+    // at least `want` streams on `device` (each created outside the lock)
+    reef_status ensure_streams(int device, size_t want) {
+        want = std::min(want, limit());
+        for (;;) {
+            {
+                std::lock_guard<std::mutex> lk(mu);
+                size_t on_device = 0;
+                for (PoolStream *p : streams) on_device += p->device == device && !p->bg_only;
+                if (on_device >= want) return REEF_OK;
+            }
+            hipError_t e = hipSuccess;
+            PoolStream *p = make(device, &e);
+            if (!p) { set_error("hipStreamCreate: %s", hipGetErrorString(e)); return REEF_ERR_HIP; }
+            std::lock_guard<std::mutex> lk(mu);
+            streams.push_back(p);                          // two threads may both add one: a stream more than wanted, never fewer
+        }
     }
     void context_destroyed() { --contexts_alive; }
 };
@@ -181,18 +283,24 @@ inline StreamPool &stream_pool() {
 // to order RCCL / torch work after it) and must not change any more.
 struct StreamLease {
     PoolStream *ps = nullptr;
-    bool counted = false, pinned = false;
+    bool counted = false, pinned = false, bg = false;
     reef_status enter(int device, hipStream_t *stream) {
         if (!counted) {
-            if (pinned && ps) ps->active.fetch_add(1, std::memory_order_relaxed);
-            else REEF_TRY(stream_pool().pick(device, &ps));
+            if (pinned && ps) {                              // its own stream for life -- but not while another context captures a graph on it
+                for (int a = ps->active.load(std::memory_order_relaxed);;) {
+                    if (a >= StreamPool::RESERVED) { std::this_thread::yield(); a = ps->active.load(std::memory_order_relaxed); continue; }
+                    if (ps->active.compare_exchange_weak(a, a + 1, std::memory_order_acq_rel)) break;
+                }
+                bg = false;
+            }
+            else REEF_TRY(stream_pool().pick(device, &ps, &bg));
             counted = true;
         }
         *stream = ps->s;
         return REEF_OK;
     }
     void idle() {
-        if (counted) StreamPool::leave(ps);
+        if (counted) StreamPool::leave(ps, bg);
         counted = false;
     }
     // from now on the context stays on one stream; only from idle (the caller of reef_msm_ctx_stream has waited for its work)

@@ -26,16 +26,7 @@ using namespace reef;
 
 namespace {
 
-struct DevGuard {
-    int prev = -1;
-    bool switched = false;
-    explicit DevGuard(int dev) {
-        if (hipGetDevice(&prev) == hipSuccess && prev != dev) switched = hipSetDevice(dev) == hipSuccess;
-    }
-    ~DevGuard() {
-        if (switched) (void)hipSetDevice(prev);
-    }
-};
+// device scopes: common.h (DeviceGuard / REEF_ON_DEVICE -- a hipSetDevice that fails is an error, never a silent wrong device)
 
 // REEF_EXCHANGE_RCCL: librccl opened at run time.  One table per process; a failed load is remembered with its message.
 struct Rccl {
@@ -224,7 +215,7 @@ static reef_status rccl_gather(reef_msm_group *g) {
         Member &mb = g->m[i];
         const size_t lead = g->rank_lead[(size_t)mb.rank];
         if (lead == i) continue;
-        DevGuard dg(mb.device);
+        REEF_ON_DEVICE(mb.device);
         REEF_HIP_TRY(hipStreamWaitEvent(g->m[lead].stream, mb.done, 0));
     }
     REEF_RCCL_TRY(R.GroupStart());
@@ -233,11 +224,13 @@ static reef_status rccl_gather(reef_msm_group *g) {
         Member &mb = g->m[i];
         ncclResult_t r;
         {
-            DevGuard dg(mb.device);
+            DeviceGuard dg(mb.device);
+            if (!dg.ok) { set_error("cannot make device %d current: %s", mb.device, hipGetErrorString(dg.err)); st = REEF_ERR_HIP; break; }
             r = R.Send(mb.partial, sizeof(reef_jacobian), ncclUint8, 0, g->comms[(size_t)mb.rank], g->m[g->rank_lead[(size_t)mb.rank]].stream);
         }
         if (r == ncclSuccess) {
-            DevGuard dg(g->m[0].device);
+            DeviceGuard dg(g->m[0].device);
+            if (!dg.ok) { set_error("cannot make device %d current: %s", g->m[0].device, hipGetErrorString(dg.err)); st = REEF_ERR_HIP; break; }
             r = R.Recv(g->gather + i, sizeof(reef_jacobian), ncclUint8, mb.rank, g->comms[0], g->m[0].stream);
         }
         if (r != ncclSuccess) { set_error("ncclSend/ncclRecv of member %zu: %s", i, R.GetErrorString(r)); st = REEF_ERR_HIP; }
@@ -250,7 +243,7 @@ static reef_status rccl_gather(reef_msm_group *g) {
 static reef_status combine(reef_msm_group *g, reef_jacobian *out) {
     const size_t nd = g->m.size();
     Member &m0 = g->m[0];
-    DevGuard dg(m0.device);
+    REEF_ON_DEVICE(m0.device);
     if (g->exchange == REEF_EXCHANGE_HOST) {
         reef_status st = REEF_OK;
         for (auto &mb : g->m) {                        // the slots are host memory: every member's last kernel must have finished
@@ -278,11 +271,11 @@ static void group_free(reef_msm_group *g) {
     if (!g) return;
     delete g->workers;                                 // joins the member threads first
     for (auto &mb : g->m)
-        if (mb.ctx) { DevGuard dg(mb.device); (void)reef_msm_ctx_sync(mb.ctx); }
+        if (mb.ctx) { DeviceGuard dg(mb.device); (void)reef_msm_ctx_sync(mb.ctx); }
     for (ncclComm_t c : g->comms)
         if (c) (void)rccl().CommDestroy(c);
     for (auto &mb : g->m) {
-        DevGuard dg(mb.device);
+        DeviceGuard dg(mb.device);
         if (mb.ctx) (void)reef_msm_ctx_sync(mb.ctx);
         reef_msm_ctx_destroy(mb.whole);
         reef_msm_ctx_destroy(mb.ctx);
@@ -291,7 +284,7 @@ static void group_free(reef_msm_group *g) {
         if (mb.stage) (void)hipFree(mb.stage);
     }
     if (!g->m.empty()) {
-        DevGuard dg(g->m[0].device);
+        DeviceGuard dg(g->m[0].device);
         if (g->gather) {
             if (g->exchange == REEF_EXCHANGE_HOST) (void)hipHostFree(g->gather);
             else (void)hipFree(g->gather);
@@ -352,7 +345,7 @@ reef_status reef_msm_group_create(reef_msm_group **out, int curve, const reef_af
                 for (size_t r = 0; r < g->rank_lead.size(); ++r)
                     if (devices[g->rank_lead[r]] == devices[i]) mb.rank = (int)r;
                 g->distinct += first_on_device;
-                DevGuard dg(mb.device);
+                REEF_ON_DEVICE(mb.device);
                 reef_msm_opts o = {};
                 if (key_opts) o = *key_opts;
                 o.device = mb.device;
@@ -415,7 +408,7 @@ reef_status reef_msm_group_create(reef_msm_group **out, int curve, const reef_af
                 }
             }
             {
-                DevGuard dg(dev0);
+                REEF_ON_DEVICE(dev0);
                 if (exchange == REEF_EXCHANGE_HOST) REEF_HIP_TRY(hipHostMalloc((void **)&g->gather, ndev * sizeof(reef_jacobian), hipHostMallocPortable | hipHostMallocMapped));
                 else REEF_HIP_TRY(hipMalloc((void **)&g->gather, ndev * sizeof(reef_jacobian)));
                 REEF_HIP_TRY(hipHostMalloc((void **)&g->landing, sizeof(reef_jacobian), hipHostMallocPortable | hipHostMallocMapped));
@@ -471,8 +464,10 @@ static reef_status split_call(reef_msm_group *g, const std::function<reef_status
     Outcome oc;
     auto one = [&](size_t i) {
         Member &mb = g->m[i];
-        DevGuard dg(mb.device);
-        reef_status st = issue(i, partial_target(g, i));
+        DeviceGuard dg(mb.device);
+        reef_status st = REEF_OK;
+        if (!dg.ok) { set_error("cannot make device %d current: %s", mb.device, hipGetErrorString(dg.err)); st = REEF_ERR_HIP; }
+        if (st == REEF_OK) st = issue(i, partial_target(g, i));
         if (st == REEF_OK) st = partial_send(g, i);
         oc.note(st);
     };
@@ -511,7 +506,8 @@ template <class Call> static reef_status dealt_rows(reef_msm_group *g, size_t ro
     auto one = [&](size_t i) {
         const size_t r0 = rows * i / nd, r1 = rows * (i + 1) / nd;
         if (r1 == r0) return;
-        DevGuard dg(g->m[i].device);
+        DeviceGuard dg(g->m[i].device);
+        if (!dg.ok) { set_error("cannot make device %d current: %s", g->m[i].device, hipGetErrorString(dg.err)); oc.note(REEF_ERR_HIP); return; }
         oc.note(call(i, r0, r1 - r0));
     };
     if (g->workers) g->workers->run(one);
@@ -593,7 +589,8 @@ reef_status reef_msm_group_rows_symbols(reef_msm_group *grp, const uint8_t *symb
             if (r1 == r0) return;
             const size_t cnt = r1 - r0;
             Member &mb = grp->m[i];
-            DevGuard dg(mb.device);
+            DeviceGuard dg(mb.device);
+            if (!dg.ok) { set_error("cannot make device %d current: %s", mb.device, hipGetErrorString(dg.err)); oc.note(REEF_ERR_HIP); return; }
             oc.note([&]() -> reef_status {
                 const void *s = symbols + r0 * row_len, *b = blinds ? blinds + r0 : nullptr, *hh = h;
                 if (symbols_loc == REEF_DEVICE && mb.device != grp->m[0].device) {

@@ -434,7 +434,7 @@ static std::string replay_devices(const Shape &shape, const std::vector<int> &or
         pp.round_constants = STANDIN_POSEIDON_RC; pp.mds = STANDIN_POSEIDON_MDS;
         pp.tag_leaf = STANDIN_POSEIDON_TAGS[0]; pp.tag_node = STANDIN_POSEIDON_TAGS[1];
         reef_fe root_d, root_1;
-        CK(reef_merkle_commit_devices(REEF_PALLAS, &pp, doc.data(), (size_t)1 << 16, false, ordinals.data(), nd, nullptr, &root_d, nullptr));      // warm-up
+        CK(reef_merkle_commit_devices(REEF_PALLAS, &pp, doc.data(), std::min(n_doc, (size_t)1 << 16), false, ordinals.data(), nd, nullptr, &root_d, nullptr));      // warm-up (never beyond the document)
         auto t0 = clk::now();
         CK(reef_merkle_commit_devices(REEF_PALLAS, &pp, doc.data(), n_doc, false, ordinals.data(), nd, nullptr, &root_d, &merkle_blocks));
         merkle_devices_ms = ms_since(t0);
@@ -473,14 +473,56 @@ static std::string replay_body(const Shape &shape, bool nofold, bool tables, con
 
     std::vector<dev_ptr<reef_affine>> owned_gens;       // destroyed after the contexts below
     std::vector<ctx_ptr> owned_ctx;
-    auto t_setup = clk::now();
+
+    // ---- set-up as a --prove run pays it.  Reef derives its commitment keys from their labels on EVERY run (src/backend/framework.rs:115,
+    // 297-303 -> CommitmentGens::new), so set-up is prove time: per curve, on a caller thread of its own -- the two curves at
+    // once -- label -> n generators on the device (row N1: reef_derive_generators; stand-in hash-to-curve parameters, replay_standins.h) ->
+    // resident pre-shifted key straight from the device buffer (reef_msm_ctx_create): what CommitmentGens(label, n, params) of
+    // reef_provider.hpp does.  Timed twice: setup_first_ms is the first pass in this process (first launches of the kernels, the
+    // workspaces' allocations), setup_ms the second.  The keys built here are dropped again: the MSMs below run on keys of the same
+    // sizes whose generators are an arithmetic progression (so that every commitment has a known discrete logarithm), built after the
+    // clock has stopped (check_keys_ms).
+    auto derive_both = [&]() {
+        std::exception_ptr err[2];
+        auto one = [&](int k) {
+            try {
+                const int id = cv[k].id;
+                reef_keygen_params kp;
+                const reef_fe *sp = id == REEF_PALLAS ? STANDIN_KEYGEN_0 : STANDIN_KEYGEN_1;
+                const char *dst = id == REEF_PALLAS ? STANDIN_KEYGEN_DST_0 : STANDIN_KEYGEN_DST_1;
+                kp.a = sp[0]; kp.b = sp[1]; kp.z = sp[2];
+                memcpy(kp.iso, sp + 3, 13 * sizeof(reef_fe));
+                kp.dst = (const uint8_t *)dst; kp.dst_len = (uint32_t)strlen(dst); kp.little_endian = 0;
+                const dev_ptr<reef_affine> gens = device_alloc<reef_affine>(cv[k].n);
+                CK(reef_derive_generators(id, (const uint8_t *)"ck", 2, cv[k].n, &kp, false, gens.get(), REEF_DEVICE));
+                reef_msm_opts o = {};
+                o.bucket_groups = 1;              // commitment keys are fixed for the life of PublicParams: pre-shift once
+                o.byte_tables = tables ? 1 : 2;   // explicit: built with the key, or never (no switch of paths mid-run)
+                o.device = -1;
+                reef_msm_ctx *key = nullptr;
+                CK(reef_msm_ctx_create(&key, id, gens.get(), cv[k].n, REEF_DEVICE, &o));
+                const ctx_ptr owner(key);
+                CK(reef_msm_ctx_sync(key));
+            } catch (...) { err[k] = std::current_exception(); }
+        };
+        auto t0 = clk::now();
+        std::thread other(one, 1);
+        one(0);
+        other.join();
+        const double ms = ms_since(t0);
+        for (auto &e : err)
+            if (e) std::rethrow_exception(e);
+        return ms;
+    };
+    const double setup_first_ms = derive_both();
+    const double setup_ms = derive_both();
+
+    auto t_check_keys = clk::now();
     for (Curve &c : cv) {
         owned_gens.push_back(device_alloc<reef_affine>(c.n));
         c.d_gens = owned_gens.back().get();
-        auto t0 = clk::now();
         c.k0 = 0xC0FFEE + c.id; c.d = 7;
         CK(reef_gen_bases(c.id, c.k0, c.d, c.n, c.d_gens, REEF_DEVICE));
-        const double gen_ms = ms_since(t0);
         {
             reef_affine g1;
             CK(reef_gen_bases(c.id, 1, 0, 1, &g1, REEF_HOST));           // 1*G
@@ -491,24 +533,18 @@ static std::string replay_body(const Shape &shape, bool nofold, bool tables, con
             owned_ctx.emplace_back(c.one);
         }
         reef_msm_opts o = {};
-        o.bucket_groups = 1;  // commitment keys are fixed for the life of PublicParams: pre-shift once
-        o.byte_tables = tables ? 1 : 2;   // explicit: built with the key, or never (no switch of paths mid-run)
+        o.bucket_groups = 1;
+        o.byte_tables = tables ? 1 : 2;
         o.device = -1;
-        t0 = clk::now();
         CK(reef_msm_ctx_create(&c.key, c.id, c.d_gens, c.n, REEF_DEVICE, &o));
         owned_ctx.emplace_back(c.key);
         CK(reef_msm_ctx_sync(c.key));
-        const double key_ms = ms_since(t0);
         reef_msm_opts plain = {};
         plain.device = -1;
-        t0 = clk::now();
         if (!nofold)   // the per-round re-keyed contexts exist only in the generator-fold IPA
             for (auto &x : c.ipa) { CK(reef_msm_ctx_create(&x, c.id, c.d_gens, c.n / 2, REEF_DEVICE, &plain)); owned_ctx.emplace_back(x); }
-        if (getenv("REEF_REPLAY_VERBOSE"))
-            fprintf(stderr, "setup curve %d: synthetic generators %.2f ms, resident pre-shifted key (%zu points) %.2f ms, plain IPA keys %.2f ms\n",
-                    c.id, gen_ms, c.n, key_ms, ms_since(t0));
     }
-    const double setup_ms = ms_since(t_setup);
+    const double check_keys_ms = ms_since(t_check_keys);
 
     // witness-like scalars for W, uniform for the cross terms T
     const dev_ptr<reef_fe> oW1 = device_scalars(REEF_PALLAS, 11, 1, cv[0].n), oT1 = device_scalars(REEF_PALLAS, 12, 0, cv[0].n);
@@ -719,23 +755,9 @@ static std::string replay_body(const Shape &shape, bool nofold, bool tables, con
         sc_step_ms = t3[1];
     }
 
-    // ---- rows N1 and N4 with STAND-IN parameters (replay_standins.h): the keys derived from a label on the GPU, and for
-    // --merkle the Poseidon tree of the document.  Timing only: parity is tests/test_gpu_keygen.py / test_gpu_merkle.py.
-    double derive_ms = 0, merkle_ms = 0;
-    for (Curve &c : cv) {
-        reef_keygen_params kp;
-        const reef_fe *sp = c.id == REEF_PALLAS ? STANDIN_KEYGEN_0 : STANDIN_KEYGEN_1;
-        const char *dst = c.id == REEF_PALLAS ? STANDIN_KEYGEN_DST_0 : STANDIN_KEYGEN_DST_1;
-        kp.a = sp[0]; kp.b = sp[1]; kp.z = sp[2];
-        memcpy(kp.iso, sp + 3, 13 * sizeof(reef_fe));
-        kp.dst = (const uint8_t *)dst; kp.dst_len = (uint32_t)strlen(dst); kp.little_endian = 0;
-        const dev_ptr<reef_affine> key_owner = device_alloc<reef_affine>(c.n);
-        reef_affine *d_key = key_owner.get();
-        CK(reef_derive_generators(c.id, (const uint8_t *)"ck", 2, c.n, &kp, false, d_key, REEF_DEVICE));   // warm-up
-        auto t0 = clk::now();
-        CK(reef_derive_generators(c.id, (const uint8_t *)"ck", 2, c.n, &kp, false, d_key, REEF_DEVICE));
-        derive_ms += ms_since(t0);
-    }
+    // ---- row N4 with STAND-IN parameters (replay_standins.h): for --merkle the Poseidon tree of the document.  Timing only: parity is
+    // tests/test_gpu_merkle.py.  (Row N1, the keys derived from their labels, is the set-up above.)
+    double merkle_ms = 0;
     if (sh->merkle_log) {
         const size_t n_doc = (size_t)1 << sh->merkle_log;
         std::vector<uint32_t> doc(n_doc);
@@ -745,7 +767,7 @@ static std::string replay_body(const Shape &shape, bool nofold, bool tables, con
         pp.round_constants = STANDIN_POSEIDON_RC; pp.mds = STANDIN_POSEIDON_MDS;
         pp.tag_leaf = STANDIN_POSEIDON_TAGS[0]; pp.tag_node = STANDIN_POSEIDON_TAGS[1];
         reef_fe root;
-        CK(reef_merkle_commit(REEF_PALLAS, &pp, doc.data(), (size_t)1 << 16, REEF_HOST, false, nullptr, REEF_HOST, &root));   // warm-up
+        CK(reef_merkle_commit(REEF_PALLAS, &pp, doc.data(), std::min(n_doc, (size_t)1 << 16), REEF_HOST, false, nullptr, REEF_HOST, &root));   // warm-up
         auto t0 = clk::now();
         CK(reef_merkle_commit(REEF_PALLAS, &pp, doc.data(), n_doc, REEF_HOST, false, nullptr, REEF_HOST, &root));
         merkle_ms = ms_since(t0);
@@ -757,15 +779,15 @@ static std::string replay_body(const Shape &shape, bool nofold, bool tables, con
     snprintf(line.data(), line.size(), "{\"replay\": \"%s\", \"ipa\": \"%s\", \"note\": \"MSM work of reef --prove replayed through the C ABI; host-side proving work not included\", "
            "\"shapes\": \"PREDICTED by Reef's cost model (src/backend/costs.rs restated in oracle/costs_oracle.py, read from %s), not measured on a Reef run\", \"w1\": %zu, \"c1\": %zu, \"w2\": %zu, \"c2\": %zu, "
            "\"scalars\": \"per-step vectors in host memory, commitments returned to the host (PCIe inclusive)\", \"commitments_checked_against_dlog\": %d, "
-           "\"key_pallas\": %zu, \"key_vesta\": %zu, \"steps\": %d, \"setup_ms\": %.3f, \"fold_steps_ms\": %.3f, \"ms_per_step\": %.3f, "
+           "\"key_pallas\": %zu, \"key_vesta\": %zu, \"steps\": %d, \"setup_ms\": %.3f, \"setup_first_ms\": %.3f, \"setup_path\": \"both curves at once, each label -> derived generators on the device -> resident pre-shifted key (Reef re-derives its keys on every --prove: framework.rs:297-303)\", \"check_keys_ms\": %.3f, \"fold_steps_ms\": %.3f, \"ms_per_step\": %.3f, "
            "\"ms_per_step_batched_pairs\": %.3f, \"ms_per_step_concurrent\": %.3f, \"ms_per_step_all_four_at_once\": %.3f, \"pairs_per_step\": %zu, \"final_snark_ms\": %.3f, \"ipa_pallas_ms\": %.3f, \"ipa_pallas_rounds\": %d, \"ipa_vesta_ms\": %.3f, "
            "\"ipa_vesta_rounds\": %d, \"consistency_ipa_ms\": %.3f, \"consistency_rounds\": %d, \"three_arguments_concurrently_ms\": %.3f, \"total_prove_msm_ms\": %.3f, "
            "\"commit_hyrax_ms\": %.3f, \"commit_hyrax_first_call_ms\": %.3f, \"sumcheck_table_log\": %d, \"sumcheck_ms_per_step\": %.3f, "
-           "\"doc_poly_bind_rows_ms\": %.3f, \"total_prove_gpu_ms\": %.3f, \"derive_both_keys_ms\": %.3f, \"commit_merkle_log\": %d, \"commit_merkle_ms\": %.3f, "
+           "\"doc_poly_bind_rows_ms\": %.3f, \"total_prove_gpu_ms\": %.3f, \"prove_gpu_incl_setup_ms\": %.3f, \"commit_merkle_log\": %d, \"commit_merkle_ms\": %.3f, "
            "\"standins\": \"key derivation and Poseidon run on stand-in parameter sets (replay_standins.h), timing only\", \"byte_tables\": %s, \"devices\": %s}",
-           sh->name.c_str(), nofold ? "cross terms over the original key (no generator fold)" : "generator fold per round", shapes_path.c_str(), sh->w1, sh->c1, sh->w2, sh->c2, g_checked, cv[0].n, cv[1].n, sh->steps, setup_ms, steps_ms, steps_ms / sh->steps, steps_batched_ms / sh->steps, steps_conc_ms / sh->steps, steps_all4_ms / sh->steps, pairs_step, final_ms, ipa1_ms, r1, ipa2_ms, r2,
+           sh->name.c_str(), nofold ? "cross terms over the original key (no generator fold)" : "generator fold per round", shapes_path.c_str(), sh->w1, sh->c1, sh->w2, sh->c2, g_checked, cv[0].n, cv[1].n, sh->steps, setup_ms, setup_first_ms, check_keys_ms, steps_ms, steps_ms / sh->steps, steps_batched_ms / sh->steps, steps_conc_ms / sh->steps, steps_all4_ms / sh->steps, pairs_step, final_ms, ipa1_ms, r1, ipa2_ms, r2,
            cons_ms, r3, concurrent_ms, steps_ms + final_ms + cons_ms, commit_ms, commit_first_ms, sh->table_log, sc_step_ms, mle_ms,
-           steps_ms + final_ms + cons_ms + sh->steps * sc_step_ms + mle_ms, derive_ms, sh->merkle_log, merkle_ms,
+           steps_ms + final_ms + cons_ms + sh->steps * sc_step_ms + mle_ms, setup_ms + steps_ms + final_ms + cons_ms + sh->steps * sc_step_ms + mle_ms, sh->merkle_log, merkle_ms,
            tables ? "\"built with the keys (inside setup_ms): MSMs of 1025..65536 points are sums of table entries\"" : "\"none (bucket pipeline)\"", devices_json.c_str());
     return std::string(line.data());        // the owners above release every context and device buffer, here or on an exception
 }

@@ -6,6 +6,7 @@
 // the key's bytes / wait).  One line of JSON per (size, threads).
 //
 // usage: seam_bench [sizes=27790,65536] [threads=1,4,8] [calls=500] [reps=5]
+//        seam_bench first=1 [sizes=4096,16384,65536] [gap_us=0,2000]     the first eight calls on a fresh key, one by one
 #include <algorithm>
 #include <atomic>
 #include <chrono>
@@ -38,12 +39,15 @@ using clk = std::chrono::steady_clock;
 
 int main(int argc, char **argv) {
     std::vector<long> sizes = {3000, 27790, 65536, 262144}, threads = {1, 4, 8};
-    long calls = 500, reps = 5;
+    long calls = 500, reps = 5, first = 0;
+    std::vector<long> gaps = {0};
     for (int i = 1; i < argc; ++i) {
         if (!strncmp(argv[i], "sizes=", 6)) sizes = list_of(argv[i] + 6);
         else if (!strncmp(argv[i], "threads=", 8)) threads = list_of(argv[i] + 8);
         else if (!strncmp(argv[i], "calls=", 6)) calls = atol(argv[i] + 6);
         else if (!strncmp(argv[i], "reps=", 5)) reps = atol(argv[i] + 5);
+        else if (!strncmp(argv[i], "first=", 6)) first = atol(argv[i] + 6);
+        else if (!strncmp(argv[i], "gap_us=", 7)) gaps = list_of(argv[i] + 7);
         else { fprintf(stderr, "usage: seam_bench [sizes=a,b] [threads=1,4,8] [calls=500] [reps=5]\n"); return 2; }
     }
     {
@@ -52,6 +56,50 @@ int main(int argc, char **argv) {
         (void)reef_runtime_init(&ro, nullptr);
     }
     if (reef_device_count() < 1) { fprintf(stderr, "seam_bench: no GPU\n"); return 3; }
+    if (first) {
+        // What a proof that folds 1-6 times pays at the seam: the FIRST calls on a fresh key, one by one.  `gap_us` of host time
+        // between the calls stands for the prover's own work between two commitments (witness synthesis, the NIFS fold; with 0 the calls are
+        // back to back -- the worst case for the builder thread, which then works beside the caller).  Every call takes the same scalars, so
+        // all results must be bit-identical whichever path served them (plain, or resident once the builder has published the key).
+        for (long gap : gaps)
+            for (long n : sizes) {
+                std::vector<reef_affine> bases((size_t)n);
+                CK(reef_gen_bases(REEF_PALLAS, 1000 + n % 89 + gap, 7, (size_t)n, bases.data(), REEF_HOST));
+                std::vector<reef_fe> sc((size_t)n);
+                CK(reef_gen_scalars(REEF_PALLAS, 33, 0, 0, (size_t)n, true, sc.data(), REEF_HOST));
+                reef_key_cache_stats st0, st1;
+                reef_key_cache_info(&st0);
+                const int ncalls = 8;
+                double ms[ncalls];
+                reef_jacobian outs[ncalls];
+                if (getenv("REEF_MSM_LOG") && atoi(getenv("REEF_MSM_LOG")) >= 2) fprintf(stderr, "seam_bench: n = %ld, gap %ld us\n", n, gap);
+                for (int i = 0; i < ncalls; ++i) {
+                    const auto t0 = clk::now();
+                    mult_pippenger_pallas(&outs[i], bases.data(), (size_t)n, sc.data(), true);
+                    ms[i] = std::chrono::duration<double, std::milli>(clk::now() - t0).count();
+                    if (getenv("REEF_MSM_LOG") && atoi(getenv("REEF_MSM_LOG")) >= 2)
+                        fprintf(stderr, "seam_bench: call %d took %.3f ms, ended at %.3f ms\n", i + 1, ms[i],
+                                (double)(std::chrono::duration_cast<std::chrono::nanoseconds>(clk::now().time_since_epoch()).count() % 100000000000ull) * 1e-6);
+                    if (gap) std::this_thread::sleep_for(std::chrono::microseconds(gap));
+                }
+                reef_key_cache_wait();
+                reef_key_cache_info(&st1);
+                bool same = true;                      // as POINTS: the Jacobian representative depends on the order of the additions
+                reef_affine aff[ncalls];
+                CK(reef_normalize(REEF_PALLAS, outs, ncalls, REEF_HOST, aff, nullptr));
+                for (int i = 1; i < ncalls; ++i) same = same && memcmp(&aff[i], &aff[0], sizeof aff[0]) == 0;
+                double sum6 = 0, mx = 0;
+                for (int i = 0; i < 6; ++i) { sum6 += ms[i]; mx = std::max(mx, ms[i]); }
+                printf("{\"what\": \"first calls on a fresh key\", \"n\": %ld, \"gap_us\": %ld, \"call_ms\": [", n, gap);
+                for (int i = 0; i < ncalls; ++i) printf("%s%.3f", i ? ", " : "", ms[i]);
+                printf("], \"sum_first_6_ms\": %.3f, \"max_of_first_6_ms\": %.3f, \"builds\": %llu, \"hits\": %llu, \"spares\": %llu, \"clones\": %llu, \"results_identical\": %s}\n",
+                       sum6, mx, (unsigned long long)(st1.builds - st0.builds), (unsigned long long)(st1.hits - st0.hits), (unsigned long long)(st1.spares - st0.spares),
+                       (unsigned long long)(st1.clones - st0.clones), same ? "true" : "false");
+                fflush(stdout);
+                if (!same) return 4;
+            }
+        return 0;
+    }
     for (long n : sizes) {
         std::vector<reef_affine> bases((size_t)n);
         CK(reef_gen_bases(REEF_PALLAS, 11 + n % 97, 3, (size_t)n, bases.data(), REEF_HOST));

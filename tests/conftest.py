@@ -47,4 +47,27 @@ def gpu_lib():
     from reef_amd import _ffi
     lib = _ffi.load()
     assert lib.reef_device_count() > 0, "no HIP device visible"
+    assert _ffi.is_release(lib) or os.environ.get("REEF_MSM_LIB"), f"the GPU suite tests the release build, not {lib.reef_version()!r}"
     return lib
+
+
+@pytest.fixture
+def experiment_build(monkeypatch):
+    """Opt-in for the few tests that FORCE a code path with an A/B switch of common.h (exp_env): for the test's duration the Python front-ends
+    bind libreef_msm_exp.so (-DREEF_EXPERIMENT).  Every other GPU test -- and bench.py -- runs on the release build, where those switches do
+    not exist."""
+    from reef_amd import _ffi
+    exp = _ffi.load_experiment()
+    assert not _ffi.is_release(exp), "libreef_msm_exp.so was built without -DREEF_EXPERIMENT"
+    monkeypatch.setattr(_ffi, "_lib", exp)
+    return exp
+
+
+@pytest.fixture(params=["release", "experiment"])
+def either_build(request, monkeypatch):
+    """Tests that set experiment switches but whose assertions are plain parity with the oracle run on BOTH builds: on the release build the
+    switches do not exist, so the same inputs go down the shipped code path."""
+    from reef_amd import _ffi
+    if request.param == "experiment":
+        monkeypatch.setattr(_ffi, "_lib", _ffi.load_experiment())
+    return request.param

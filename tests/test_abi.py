@@ -17,12 +17,16 @@ def test_library_present_and_loads():
     assert lib.reef_abi_version() == header == _ffi.ABI_VERSION          # header, binding and binary agree
 
 
-def test_in_tree_build_is_the_experiment_build_and_says_so():
-    """The A/B switches (common.h: exp_env) exist only in builds with -DREEF_EXPERIMENT -- the in-tree build the tests and tools load;
-    `make -C reef_amd/csrc release` compiles them out.  The version string tells the two apart."""
-    assert b"+experiment" in _ffi.load().reef_version()
+def test_the_loaded_build_is_the_release_build_and_says_so():
+    """The A/B switches (common.h: exp_env) exist only in builds with -DREEF_EXPERIMENT.  Since round 6 the library the binding loads -- the one
+    bench.py measures and the GPU suite tests -- is the RELEASE build (reef_amd/_lib/libreef_msm.so); the switches live in libreef_msm_exp.so,
+    bound only by load_experiment().  The version string tells the two apart."""
+    if not os.environ.get("REEF_MSM_LIB"):
+        assert _ffi.is_release() and b"release" in _ffi.load().reef_version()
+    assert b"+experiment" in _ffi.load_experiment().reef_version()
+    assert _ffi.load_experiment().reef_abi_version() == _ffi.load().reef_abi_version()
     mk = open(os.path.join(_ffi.CSRC, "Makefile")).read()
-    assert "EXPERIMENT ?= 1" in mk and "release:" in mk and "-DREEF_EXPERIMENT" in mk
+    assert "libreef_msm_exp.so" in mk and "release:" in mk and "-DREEF_EXPERIMENT" in mk
     common = open(os.path.join(_ffi.CSRC, "common.h")).read()
     import glob
     import re

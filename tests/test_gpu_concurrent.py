@@ -16,7 +16,7 @@ def cache_info():
     from reef_amd import _ffi
     st = _ffi.KeyCacheStats()
     _ffi.load().reef_key_cache_info(ctypes.byref(st))
-    return {n: getattr(st, n) for n, _ in st._fields_ if n != "reserved"}
+    return {n: getattr(st, n) for n, _ in st._fields_}
 
 
 def run_threads(nthreads, fn):
@@ -64,6 +64,7 @@ def test_eight_threads_share_one_key(gpu_lib, cref, cases):
                         got = msm.compress(cid, msm.mult_pippenger(cid, bases, scal[j]))
                         assert got == want[j], (cid, n, generation, t, rep)
                 run_threads(8, work)
+                gpu_lib.reef_key_cache_wait()           # round 6: the resident copy is built beside the callers; generations 1 and 2 find it published
     after = cache_info()
     cached_keys = 2 * sum(1 for n in SIZES if n >= 1024)
     assert after["builds"] - before["builds"] == cached_keys, (before, after)       # one build per key, not one per thread
@@ -105,6 +106,9 @@ def test_keys_that_differ_in_one_unsampled_point(n, gpu_lib, cref):
     want = {0: cref.compress(cid, cref.msm_pippenger(cid, a, sc, threads=8)), 1: cref.compress(cid, cref.msm_pippenger(cid, b, sc, threads=8))}
     assert want[0] != want[1]
     before = cache_info()
+    for which in (0, 1, 0, 1):                                 # both keys seen twice: the builder thread makes them resident
+        assert msm.compress(cid, msm.mult_pippenger(cid, (a, b)[which], sc)) == want[which]
+    gpu_lib.reef_key_cache_wait()
 
     def work(t):
         for rep in range(8):
@@ -207,18 +211,21 @@ def test_an_evicted_key_stays_charged_while_a_thread_is_attached_to_it(gpu_lib, 
     a, b = cref.gen_bases_ap(cid, 9100, 3, n), cref.gen_bases_ap(cid, 9200, 3, n)
     sc = cref.gen_scalars(cid, 3, n)
     per = 64 * n * msm.plan_for(n, bucket_groups=1)["tables"]
-    for _ in range(3):
-        msm.mult_pippenger(cid, b, sc)                 # resident from the third call on; this thread's context is attached to b
+    def three_calls(key):
+        for i in range(3):
+            msm.mult_pippenger(cid, key, sc)           # the second call hands the key to the builder thread; the third finds it resident
+            if i == 1:
+                gpu_lib.reef_key_cache_wait()
+    three_calls(b)                                     # this thread's context is attached to b
     gpu_lib.reef_key_cache_clear()
     r0 = cache_info()
     assert r0["entries"] == 0 and r0["resident_keys"] == 0 and r0["resident_bytes"] >= per       # b left the table but is still pinned, and still charged
-    for _ in range(3):
-        msm.mult_pippenger(cid, a, sc)                 # the context moves to a: b's tables are freed, a's are charged
+    three_calls(a)                                     # the thread lets go of b at its next call (the table's epoch): b's tables are freed, a's are charged
     r1 = cache_info()
     assert r1["resident_bytes"] == r0["resident_bytes"] and r1["resident_keys"] == 1
     gpu_lib.reef_key_cache_clear()
     assert cache_info()["resident_bytes"] == r0["resident_bytes"] and cache_info()["entries"] == 0
-    t = threading.Thread(target=lambda: [msm.mult_pippenger(cid, b, sc) for _ in range(3)])     # another thread builds b and ends: its attachment goes with it
+    t = threading.Thread(target=lambda: three_calls(b))     # another thread brings b back and ends: its attachment goes with it
     t.start()
     t.join()
     r2 = cache_info()
@@ -230,3 +237,32 @@ def test_an_evicted_key_stays_charged_while_a_thread_is_attached_to_it(gpu_lib, 
             break
         time.sleep(0.01)
     assert cache_info()["resident_bytes"] == r0["resident_bytes"]                                # b had no other holder: freed with its entry
+
+
+@pytest.mark.parametrize("n", [4096, 27790])
+def test_first_calls_on_a_fresh_key(n, gpu_lib, cref):
+    """what a proof with 1-6 folding steps sees.  Six calls on a key the process has never seen, every result against the
+    C oracle whichever path served it (plain while the builder thread works, resident once it has published the key); other threads call on
+    the same key WHILE it is being built; exactly one resident copy is built and the builder's spare context serves the first hit."""
+    from reef_amd import msm
+    cid = 0
+    bases = cref.gen_bases_ap(cid, 424242 + n, 11, n)
+    scal = [cref.gen_scalars(cid, 300 + j, n, kind=j % 2) for j in range(3)]
+    want = [cref.compress(cid, cref.msm_pippenger(cid, bases, s, threads=8)) for s in scal]
+    before = cache_info()
+    for i in range(2):                                                         # the second appearance hands the key to the builder thread
+        assert msm.compress(cid, msm.mult_pippenger(cid, bases, scal[i % 3])) == want[i % 3], i
+
+    def work(t):                                                               # beside the build: served on the plain path, or on the fresh copy
+        for rep in range(3):
+            j = (t + rep) % 3
+            assert msm.compress(cid, msm.mult_pippenger(cid, bases, scal[j])) == want[j], (t, rep)
+    run_threads(4, work)
+    for i in range(2, 6):
+        assert msm.compress(cid, msm.mult_pippenger(cid, bases, scal[i % 3])) == want[i % 3], i
+    gpu_lib.reef_key_cache_wait()
+    assert msm.compress(cid, msm.mult_pippenger(cid, bases, scal[0])) == want[0]
+    after = cache_info()
+    assert after["builds"] - before["builds"] == 1, (before, after)
+    assert after["spares"] - before["spares"] == 1 and after["hits"] > before["hits"], (before, after)
+    assert after["misspeculated"] == before["misspeculated"]

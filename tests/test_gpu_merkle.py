@@ -105,15 +105,16 @@ def test_sparse_partial_rounds_equal_the_dense_definition(rp, gpu_lib):
 
 
 def test_dense_form_kept_behind_the_switch(gpu_lib):
-    """REEF_POSEIDON_DENSE=1 (read once per process) keeps the defining dense rounds: same tree."""
+    """REEF_POSEIDON_DENSE=1 (an experiment switch, read once per process: the experiment build in a child) keeps the defining dense rounds: same tree."""
     import os
     import subprocess
     import sys
+    from reef_amd import _ffi
     code = ("import sys; sys.path.insert(0, '.');\n"
             "from oracle import merkle_oracle as M\nfrom reef_amd import merkle\n"
             "p = M.standin_params(); doc = list(range(2, 40))\n"
             "assert merkle.commit('pallas', doc, p.t, p.rf, p.rp, p.rc, p.mds, p.tag_leaf, p.tag_node) == M.commit(doc, p)\nprint('dense-ok')\n")
-    out = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, REEF_POSEIDON_DENSE="1"), capture_output=True, text=True, timeout=300,
+    out = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, REEF_POSEIDON_DENSE="1", REEF_MSM_LIB=_ffi.EXPERIMENT_LIB_PATH), capture_output=True, text=True, timeout=300,
                          cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     assert "dense-ok" in out.stdout, out.stderr[-2000:]
 

@@ -1,9 +1,9 @@
-"""The RELEASE build (`make -C reef_amd/csrc release` -> reef_amd/_lib/libreef_msm_release.so: the library an embedder ships, without
--DREEF_EXPERIMENT, so none of the A/B switches of common.h exist in it) computes what the in-tree experiment build computes.  The rest
-of the GPU suite loads the experiment build (its tests drive those switches); here a fresh interpreter loads the release build through
-REEF_MSM_LIB and runs (1) __graft_entry__.smoke() -- every row of the path against the oracle -- and (2) MSMs at Reef's sizes and at the
-bench size against their discrete logarithms, plus a switch that must NOT be read.  Skipped when the release build is absent or older
-than the sources (build(): the driver's build check compiles the experiment build only; `make release` adds three minutes)."""
+"""Two builds of the same sources (reef_amd/csrc/Makefile).  reef_amd/_lib/libreef_msm.so is the RELEASE build -- no -DREEF_EXPERIMENT, so none of
+the A/B switches of common.h exist in it: the library an embedder ships, and since round 6 the one reef_amd/_ffi.py loads, bench.py measures and
+this whole GPU suite tests.  libreef_msm_exp.so carries the switches for the few tests that force a code path (conftest.py: experiment_build).
+Here: (1) the suite's library really is the release build and does not even contain the switches' names; (2) a fresh interpreter loads the
+EXPERIMENT build through REEF_MSM_LIB and runs __graft_entry__.smoke() -- every row of the path against the oracle -- and MSMs at Reef's sizes and
+at the bench size against their discrete logarithms: with no switch set it computes what the release build computes."""
 import glob
 import os
 import subprocess
@@ -15,7 +15,8 @@ from reef_amd import _ffi
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-RELEASE = os.path.join(os.path.dirname(_ffi.LIB_PATH), "libreef_msm_release.so")
+RELEASE = os.path.join(os.path.dirname(_ffi.EXPERIMENT_LIB_PATH), "libreef_msm.so")
+EXPERIMENT = _ffi.EXPERIMENT_LIB_PATH
 
 CHILD = r"""
 import os, sys
@@ -25,7 +26,7 @@ import __graft_entry__ as g
 from reef_amd import _ffi, msm
 lib = _ffi.load()
 ver = lib.reef_version().decode()
-assert _ffi.LIB_PATH.endswith("libreef_msm_release.so") and "+experiment" not in ver, (ver, _ffi.LIB_PATH)
+assert _ffi.LIB_PATH.endswith("libreef_msm_exp.so") and "+experiment" in ver, (ver, _ffi.LIB_PATH)
 g.smoke()
 from oracle.pasta_oracle import CURVES
 sys.path.insert(0, os.environ["REEF_ROOT"])
@@ -42,24 +43,31 @@ for curve, logn in (("pallas", 15), ("vesta", 14), ("pallas", 20)):
             out = np.zeros(12, dtype=np.uint64)
             ctx.msm(sc, n, out=out)
             assert msm.compress(curve, out) == want, (curve, logn, groups)
-print("release ok:", ver)
+print("experiment build ok:", ver)
 """
 
 
-def _fresh():
-    if not os.path.exists(RELEASE):
+def _fresh(path):
+    if not os.path.exists(path):
         return False
     srcs = [f for pat in ("*.inc", "*.h", "*.hip", "*.cpp", "Makefile") for f in glob.glob(os.path.join(_ffi.CSRC, pat))] + [_ffi.HEADER]
-    return os.path.getmtime(RELEASE) >= max(os.path.getmtime(f) for f in srcs)
+    return os.path.getmtime(path) >= max(os.path.getmtime(f) for f in srcs)
 
 
-@pytest.mark.skipif(not _fresh(), reason="reef_amd/_lib/libreef_msm_release.so absent or older than the sources: make -C reef_amd/csrc release")
-def test_release_build_matches_the_oracle(gpu_lib):
-    # REEF_MSM_WIDE=1 is a supported switch (byte tables by policy); REEF_MSM_SORT_COMPACT is an experiment switch the release build must not know
-    env = dict(os.environ, REEF_MSM_LIB=RELEASE, REEF_ROOT=ROOT, REEF_MSM_SORT_COMPACT="0")
-    out = subprocess.run([sys.executable, "-c", CHILD], capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
-    assert out.returncode == 0, out.stderr[-3000:]
-    assert "smoke ok" in out.stdout and "release ok: reef_msm" in out.stdout
+def test_the_suite_runs_on_the_release_build(gpu_lib):
+    ver = gpu_lib.reef_version().decode()
+    assert "release" in ver and "+experiment" not in ver, ver
+    assert os.path.samefile(_ffi.LIB_PATH, RELEASE) or os.environ.get("REEF_MSM_LIB")
+    assert _fresh(RELEASE), "reef_amd/_lib/libreef_msm.so is older than the sources: python -c 'import __graft_entry__ as g; g.build()'"
     raw = open(RELEASE, "rb").read()
     assert b"REEF_MSM_SORT_COMPACT" not in raw and b"REEF_SC_BLOCKS" not in raw        # the experiment switches' names are not even in the binary
     assert b"REEF_MSM_KEY_CACHE" in raw                                               # the supported ones are
+    assert b"REEF_MSM_SORT_COMPACT" in open(EXPERIMENT, "rb").read()
+
+
+def test_experiment_build_matches_the_oracle(gpu_lib):
+    assert _fresh(EXPERIMENT), "reef_amd/_lib/libreef_msm_exp.so absent or older than the sources"
+    env = dict(os.environ, REEF_MSM_LIB=EXPERIMENT, REEF_ROOT=ROOT)
+    out = subprocess.run([sys.executable, "-c", CHILD], capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-3000:]
+    assert "smoke ok" in out.stdout and "experiment build ok: reef_msm" in out.stdout

@@ -178,7 +178,7 @@ def test_fused_fold_and_next_coeffs(gpu_lib):
     ("pallas", 12, {"REEF_SC_SPLIT_MAX": "64", "REEF_SC_ITEMS": "3", "REEF_SC_FLOOR": "1", "REEF_SC_BLOCKS": "5"}),   # grid-stride tails in the dense kernels
     ("pallas", 13, {"REEF_SC_ONE_LAUNCH": "0"}),                                     # every round through the second kernel (the split form is a one-launch form: off)
 ])
-def test_small_and_mid_round_grids(curve, ell, env, gpu_lib, monkeypatch):
+def test_small_and_mid_round_grids(curve, ell, env, gpu_lib, experiment_build, monkeypatch):
     """The round-4 grids of the dense rounds -- an item's four folds and three products on the four waves of a workgroup
     (k_sc_fold_coeffs_split), several pairs per thread in the mid-sized rounds, the wave sums through DPP, limb sums folded back by
     fe_from_limb_sums -- against the oracle round by round, with the edge challenges 0, 1 and q - 1 among the random ones and a
@@ -212,7 +212,7 @@ def test_small_and_mid_round_grids(curve, ell, env, gpu_lib, monkeypatch):
 @pytest.mark.parametrize("curve,ell,n_t,nq,fused", [("pallas", 2, 3, 1, False), ("pallas", 3, 8, 3, True), ("pallas", 7, 100, 9, True),
                                                      ("pallas", 11, 2000, 40, True), ("pallas", 12, 1 << 12, 33, False),
                                                      ("vesta", 9, 300, 5, True), ("pallas", 10, 1 << 10, 0, True)])
-def test_rank_one_eq_rounds_vs_oracle(curve, ell, n_t, nq, fused, gpu_lib, monkeypatch):
+def test_rank_one_eq_rounds_vs_oracle(curve, ell, n_t, nq, fused, gpu_lib, experiment_build, monkeypatch):
     """gen_eq_table's table kept as FH (x) FL + point masses while the rounds fold FH bits (never written out): forced on at
     sizes the oracle handles (by default it serves tables of 2^22 entries and more), every round's coefficients, the folded
     tables, a look at EQ between rounds, repeated and colliding lookup indices, masses in both halves."""
@@ -259,7 +259,7 @@ def test_rank_one_eq_rounds_vs_oracle(curve, ell, n_t, nq, fused, gpu_lib, monke
             assert sc.read(0, 1) == [tt[0]] and sc.read(1, 1) == [ee[0]]
 
 
-def test_rank_one_matches_dense_at_default_size(gpu_lib, monkeypatch):
+def test_rank_one_matches_dense_at_default_size(gpu_lib, experiment_build, monkeypatch):
     """2^22 entries (the smallest table the rank-one rounds serve by default): the transcript of a whole folding step equals the
     dense form's (REEF_SC_RANK1=0), the sum-check identity holds round after round, and the final claim is T~(r) * EQ~(r)."""
     from reef_amd.sumcheck import SumCheck
@@ -338,7 +338,7 @@ def _structured_table(kind, ell, rng, q):
 
 @pytest.mark.parametrize("kind,ell,nq,fused", [("hybrid", 10, 7, True), ("hybrid", 11, 40, True), ("document", 8, 3, True), ("mixed", 10, 9, True),
                                                ("mixed", 12, 33, False), ("hybrid", 6, 2, True), ("mixed", 7, 5, True)])
-def test_structured_pristine_table_vs_oracle(kind, ell, nq, fused, gpu_lib, monkeypatch):
+def test_structured_pristine_table_vs_oracle(kind, ell, nq, fused, gpu_lib, experiment_build, monkeypatch):
     """The first round of a folding step on a table with constant rows and rows of small entries (closed forms, 4-byte reads),
     forced on at sizes the oracle handles: coefficients of every round, the folded table after the first fold, two steps."""
     from reef_amd.sumcheck import SumCheck
@@ -387,7 +387,7 @@ def test_structured_pristine_table_vs_oracle(kind, ell, nq, fused, gpu_lib, monk
 @pytest.mark.parametrize("kind,ell,nq", [("hybrid", 10, 7), ("hybrid", 12, 33), ("document", 8, 5), ("document", 11, 20), ("mixed", 10, 9), ("mixed", 13, 17),
                                          ("hybrid", 6, 2), ("hybrid", 7, 3)])
 @pytest.mark.parametrize("interrupt", ["none", "read", "unfused", "coeffs", "set_eq"])
-def test_deferred_first_fold(kind, ell, nq, interrupt, gpu_lib, monkeypatch):
+def test_deferred_first_fold(kind, ell, nq, interrupt, gpu_lib, either_build, monkeypatch):
     """Round 4: the first fold of a structured table is deferred by one round for the rows whose next fold has only constant / small
     sources too -- round two's sums come from the pristine rows with scaled row factors, the second fold writes a quarter-size table
     straight from the 4-byte sources.  Every round's coefficients against the oracle with NOTHING read in between (so that the
@@ -441,7 +441,7 @@ def test_deferred_first_fold(kind, ell, nq, interrupt, gpu_lib, monkeypatch):
 
 
 @pytest.mark.parametrize("kind,ell,nq", [("hybrid", 10, 7), ("mixed", 9, 4)])
-def test_gen_eq_before_set_table_gives_the_same_step(kind, ell, nq, gpu_lib, monkeypatch):
+def test_gen_eq_before_set_table_gives_the_same_step(kind, ell, nq, gpu_lib, experiment_build, monkeypatch):
     """The results do not depend on the order of the calls (include/reef_msm.h 3b): gen_eq_table FIRST, then a structured table --
     and a structured table that replaces an unstructured one after gen_eq_table -- give the coefficients of the reference order
     (the sum of FL that constant rows need is taken in gen_eq_table whether or not a structure is known then: ADVICE r3)."""
@@ -475,7 +475,7 @@ def test_gen_eq_before_set_table_gives_the_same_step(kind, ell, nq, gpu_lib, mon
             assert sc.read(0, 1) == [tt[0]] and sc.read(1, 1) == [ee[0]]
 
 
-def test_structured_table_at_cfg4_shape(gpu_lib, monkeypatch):
+def test_structured_table_at_cfg4_shape(gpu_lib, experiment_build, monkeypatch):
     """2^24 entries shaped like the hybrid table of BASELINE's cfg4 (first half: a few transition rows, then one value; second
     half: DNA symbols, then zeros): the transcript of a folding step equals the one taken without the structure and the dense one."""
     from reef_amd.sumcheck import SumCheck
