@@ -1,7 +1,7 @@
 // sc_stress -- the one-launch sum-check rounds under load, through the C ABI only.
 //
 // A multi-block one-launch round (reef_amd/csrc/sumcheck_kernels.inc: sc_round_epilogue) hands the blocks' sums to the last block
-// through device-scope atomics; by default nothing but the return of those atomics orders them before the ticket (REEF_SC_FENCE=0).
+// through device-scope atomics; by default the ticket is an acq_rel read-modify-write (REEF_SC_FENCE=2); with REEF_SC_FENCE=0 nothing but the return of those atomics orders them before the ticket.
 // Functional tests do not find a once-in-10^6 ordering bug, so this program repeats ONE folding step (reef_sc_gen_eq_table, then
 // every round fused: src/backend/r1cs_helper.rs:441-544) thousands of times with the same inputs and compares every coefficient
 // triple with the transcript of the two-launch form (REEF_SC_ONE_LAUNCH=0: a second kernel adds the blocks' sums after a kernel

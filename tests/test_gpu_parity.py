@@ -900,3 +900,43 @@ print('graph-ok')
     out = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, REEF_MSM_GRAPH="1"), capture_output=True, text=True, timeout=600,
                          cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     assert "graph-ok" in out.stdout, out.stderr[-3000:]
+
+
+@pytest.mark.parametrize("name", ["pallas", "vesta"])
+def test_plain_key_results_that_stay_on_the_device(name, gpu_lib, cref):
+    """Round 6: a plain key (no pre-shifted tables: pasta-msm's contract, and what the IPA's folded bases get) with the RESULT LEFT ON THE DEVICE.  The window
+    combine -- ~255 dependent doublings -- is finished by a host function enqueued on the context's stream (hipLaunchHostFunc) and copied back in stream
+    order, so the call still only enqueues work.  Several calls back to back on one context before anything is waited for (each host function must see
+    ITS group sums), device and host scalars, a prefix of the key, window splits, and a window so small that the group sums do not fit the landing zone
+    (the on-device Horner kernel takes over)."""
+    from reef_amd import msm
+    cid = msm.curve_id(name)
+    for n, wbits in ((1, 0), (777, 0), (5000, 0), (40000, 0), (3000, 3), (3000, 2)):
+        bases = cref.gen_bases_ap(cid, 2024 + n, 3, n)
+        bases[n // 2] = 0
+        scs = [cref.gen_scalars(cid, 50 + j, n, kind=j % 2) for j in range(4)]
+        want = [cref.compress(cid, cref.msm_pippenger(cid, bases, s, threads=8)) for s in scs]
+        with msm.MsmContext(cid, bases, bucket_groups=0, window_bits=wbits) as ctx:
+            outs = [msm.DeviceBuffer(96) for _ in scs]
+            dsc = [msm.DeviceBuffer.from_host(s) for s in scs[:2]]
+            for rep in range(2):
+                for j in range(4):                                   # enqueued one after the other, nothing waited for in between
+                    ctx.msm(dsc[j] if j < 2 else scs[j], n, out=outs[j])
+                ctx.sync()
+                for j in range(4):
+                    assert msm.compress(cid, outs[j].to_host((12,))) == want[j], (n, wbits, rep, j)
+            if n > 10:
+                m = n - 7
+                ctx.msm(scs[1][:m].copy(), m, out=outs[0])
+                ctx.sync()
+                assert msm.compress(cid, outs[0].to_host((12,))) == cref.compress(cid, cref.msm_pippenger(cid, bases[:m].copy(), scs[1][:m].copy(), threads=8))
+                parts = []
+                for r in range(3):                                    # window split: the partial sums stay on the device too
+                    ctx.set_window_split(r, 3)
+                    ctx.msm(dsc[0], n, out=outs[r])
+                ctx.sync()
+                parts = [outs[r].to_host((12,)) for r in range(3)]
+                assert msm.compress(cid, msm.sum_points(cid, np.stack(parts))) == want[0], (n, wbits)
+                ctx.set_window_split(0, 1)
+            for b in outs + dsc:
+                b.free()
