@@ -516,6 +516,56 @@ def single_process_main(a):
         for g in gs:
             g.close()
     strong["speedup_vs_1"] = {"windows": one_gpu_ms / strong["windows_ms_per_step"], "points": one_gpu_ms / strong["points_ms_per_step"]}
+    # ---- where one split call's time goes (round 6: the first run on several physical devices cannot be rehearsed, so the line itemises it and sets the
+    # model's figure beside each term): one call in flight, medians of 9 calls, reef_msm_group_last_timing
+    import statistics
+    hs1 = sc1.to_host((n, 4))
+
+    def phases(group, scal):
+        group.enable_timing(True)
+        rows = []
+        for _ in range(11):
+            r = group.msm(scal, n)
+            rows.append(group.last_timing())
+        group.enable_timing(False)
+        rows = rows[2:]
+        med = lambda f: statistics.median(f(t) for t in rows)                                       # noqa: E731
+        return {"total_ms": med(lambda t: t["total_ms"]), "scalar_distribution_ms": med(lambda t: t["distribute_ms"]),
+                "member_msm_ms": {"max": med(lambda t: max(t["member_stream_ms"])), "min": med(lambda t: min(t["member_stream_ms"]))},
+                "member_issue_ms": {"max": med(lambda t: max(t["member_issue_ms"])), "min": med(lambda t: min(t["member_issue_ms"]))},
+                "members_finish_after_distribution_ms": med(lambda t: max(0.0, t["members_done_ms"] - t["distribute_ms"])),
+                "exchange_ms": med(lambda t: t["combine_ms"]),
+                "exchange_note": "the members' 96-byte sends ride on their own streams (inside member_msm_ms); exchange_ms is what is left once every member has finished: "
+                                 "the sum of the partial sums on devices[0] and its way to the host"}, r
+    # DESIGN.md 7 "Predicted scaling": stage costs of one 2^20-point MSM alone on one GPU (us): recode 32, sort 260 of which 60 do not shrink with the digits,
+    # accumulation 1050, merge 70, bucket reduction 160, exchange + N-1 additions 25; scaled to this run's one-GPU latency
+    alone_ms = strong.get("windows_latency_ms") if N == 1 else None
+    model_one = 32 + 260 + 1050 + 70 + 160
+    pred = {"windows_latency_ms": (32 + 60 + (200 + 1050) / N + 70 + 160 + 25) / 1e3 * (n / (1 << 20) if n < (1 << 20) else 1.0),
+            "points_latency_ms": (0.30 + (model_one / 1e3 - 0.30) / N + 0.025),
+            "basis": "DESIGN.md 7 (stage costs of one 2^20-point MSM alone on one GPU from profiles/r02_msm_kernel_timelines.txt; the host scalars' upload is NOT in the "
+                     "model: 32 MiB over one PCIe link ~0.6 ms pinned, 2-4 ms pageable -- compare scalar_distribution_ms)"}
+    ph = {"predicted": pred, "protocol": "one call in flight, medians of 9 timed calls (reef_msm_group_enable_timing: every member is waited for separately before the sum)"}
+    for name, sp in (("windows", msm.SPLIT_WINDOWS), ("points", msm.SPLIT_POINTS)):
+        for mode_name, mode in (("each_member_uploads", msm.SCALARS_EACH), ("fanout_from_member_0", msm.SCALARS_FANOUT)):
+            if sp == msm.SPLIT_POINTS and mode == msm.SCALARS_FANOUT:
+                continue
+            try:
+                with msm.MsmGroup(a.curve, bases1, devices, n, split=sp, exchange=EX, window_bits=a.window_bits, bucket_groups=groups_opt, chunk=a.chunk, scalars=mode) as g:
+                    g.msm(hs1)
+                    g.msm(sc1, n)
+                    entry = {}
+                    entry["host_scalars"], r_h = phases(g, hs1)
+                    if mode == msm.SCALARS_EACH:
+                        entry["device_scalars"], r_d = phases(g, sc1)
+                        if want1 is not None:
+                            check_ok = check_ok and msm.compress(a.curve, r_d) == want1
+                    if want1 is not None:
+                        check_ok = check_ok and msm.compress(a.curve, r_h) == want1
+                    ph[name + ("" if mode == msm.SCALARS_EACH else "_" + mode_name)] = entry
+            except Exception as e:                              # instrumentation never takes the line down
+                ph[name + "_" + mode_name] = {"error": str(e)}
+    strong["phases"] = ph
     strong["note"] = ("ONE 2^logn-point MSM over the members of a device group of THIS process: windows = member i accumulates the Pippenger windows "
                       "w = i (mod N) on a replicated key (north_star's split), points = contiguous slices; *_ms_per_step with `in_flight` groups called from as "
                       "many threads, *_latency_ms with one; one_gpu_ms_per_msm is one context per call on devices[0] under the same protocol")
@@ -935,6 +985,33 @@ def main():
                 dist.all_reduce(t_, op=dist.ReduceOp.MAX)
                 return float(t_.item()) / ksteps * 1e3, results[(ksteps - 1) % len(cs)].cpu().numpy().copy()
 
+            def phases_of(c, x, sc_ptr, cnt):
+                """Where ONE split MSM's time goes on this run's ranks (round 6: the first SCALE line must be diagnosable): one call in flight, 9 timed
+                repetitions, per rank the host-timed MSM (enqueue to the partial sum finished) and exchange (all-gather of the 96-byte partial sums + the
+                on-device sum, to finished); medians per rank, then max / min over the ranks."""
+                import statistics
+                ms_, ex_ = [], []
+                for it in range(11):
+                    dist.barrier()
+                    t0p = time.perf_counter()
+                    c.msm(sc_ptr, cnt, out=parts[0].data_ptr())
+                    c.sync()
+                    t1p = time.perf_counter()
+                    x.combine(parts[0], gathered[0], results[0])
+                    c.sync()
+                    torch.cuda.synchronize()
+                    t2p = time.perf_counter()
+                    if it >= 2:
+                        ms_.append((t1p - t0p) * 1e3)
+                        ex_.append((t2p - t1p) * 1e3)
+                mine = torch.tensor([statistics.median(ms_), statistics.median(ex_)], dtype=torch.float64, device=cdev0)
+                allp = [torch.zeros_like(mine) for _ in range(world)]
+                dist.all_gather(allp, mine)
+                m_ = [float(t[0]) for t in allp]
+                e_ = [float(t[1]) for t in allp]
+                return {"member_msm_ms": {"max": max(m_), "min": min(m_), "per_rank": m_}, "exchange_ms": {"max": max(e_), "min": min(e_)},
+                        "note": "exchange_ms contains the wait for the slowest rank's partial sum (a rank that finishes early waits in the all-gather)"}
+
             # rank 0's points and scalars are THE MSM; the other ranks generate the same ones (seeded, on the device)
             bases0 = bases if rank == 0 else msm.gen_bases(a.curve, k0, d, n, device=True)
             scal0 = scalars if rank == 0 else msm.gen_scalars(a.curve, 0x5EEF, n, kind=kind, mont=True, device=True)
@@ -944,14 +1021,24 @@ def main():
                 wfirst = msm.MsmContext(a.curve, bases0, n, window_bits=a.window_bits, bucket_groups=groups, chunk=a.chunk)
             wfirst.set_window_split(rank, world)
             wctx = [wfirst] + [wfirst.clone() for _ in range(nctx - 1)]          # clones inherit the split
-            w_ms, w_res = timed(wctx, [make_exch(c) for c in wctx], scal0, n)
+            wx = [make_exch(c) for c in wctx]
+            w_ms, w_res = timed(wctx, wx, scal0, n)
+            try:
+                w_phases = phases_of(wctx[0], wx[0], scal0, n)
+            except Exception as e:
+                w_phases = {"error": str(e)}
             for c in wctx:
                 c.close()
             lo, hi = shard_bounds(n, world, rank)
             bases_s = msm.gen_bases(a.curve, k0 + lo * d, d, hi - lo, device=True)
             pfirst = msm.MsmContext(a.curve, bases_s, hi - lo, window_bits=a.window_bits, bucket_groups=groups, chunk=a.chunk)
             pctx = [pfirst] + [pfirst.clone() for _ in range(nctx - 1)]
-            p_ms, p_res = timed(pctx, [make_exch(c) for c in pctx], scal0.ptr + 32 * lo, hi - lo)
+            px = [make_exch(c) for c in pctx]
+            p_ms, p_res = timed(pctx, px, scal0.ptr + 32 * lo, hi - lo)
+            try:
+                p_phases = phases_of(pctx[0], px[0], scal0.ptr + 32 * lo, hi - lo)
+            except Exception as e:
+                p_phases = {"error": str(e)}
             for c in pctx:
                 c.close()
             one_gpu_ms = elapsed / (a.steps * MPS) * 1e3      # what one GPU needs for a 2^logn-point MSM in the same regime (the weak region above)
@@ -959,6 +1046,11 @@ def main():
                       "windows_ms_per_step": w_ms, "points_ms_per_step": p_ms,
                       "speedup_vs_1": {"windows": one_gpu_ms / w_ms, "points": one_gpu_ms / p_ms},
                       "one_gpu_ms_per_msm": one_gpu_ms,
+                      "phases": {"windows": w_phases, "points": p_phases,
+                                 "predicted": {"windows_member_msm_ms": (32 + 60 + (200 + 1050) / world + 70 + 160) / 1e3, "points_member_msm_ms": 0.30 + 1.27 / world,
+                                               "exchange_ms": 0.025, "windows_ms_per_step_in_flight": {1: 1.33, 2: 0.85, 4: 0.58, 8: 0.45}.get(world),
+                                               "basis": "DESIGN.md 7 'Predicted scaling' (stage costs of one 2^20-point MSM on one GPU, us: recode 32, sort 260 of which 60 fixed, "
+                                                        "accumulation 1050, merge 70, bucket reduction 160, all-gather + N-1 additions 25)"}},
                       "note": "ONE 2^logn-point MSM split over the ranks (strong scaling), timed after the weak-scaling region with the same barrier + "
                               "max-over-ranks protocol; windows = reef_msm_ctx_set_window_split(rank, N) on replicated points and scalars, points = "
                               "contiguous slices; one_gpu_ms_per_msm is the weak region's time per MSM (a 2^logn-point MSM per GPU); the *_ms_per_step figures here are per MSM"}

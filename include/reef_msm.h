@@ -22,7 +22,8 @@
  *
  * ABI changelog (reef_abi_version()):
  *   6  round 6: the drop-in symbols build a returning key's resident copy on a builder thread (no call pays for it: reef_key_cache_wait,
- *      reef_key_cache_stats.spares in place of .reserved); REEF_SC_FENCE defaults to the release-ordered ticket.
+ *      reef_key_cache_stats.spares in place of .reserved); REEF_SC_FENCE defaults to the release-ordered ticket; device groups report where a
+ *      call's time went (reef_msm_group_enable_timing / _last_timing) and take REEF_SCALARS_FANOUT (reef_msm_group_opts.scalars, was reserved[0]).
  *   5  round 5: device groups (reef_msm_group_*: one MSM split by window or by points, or the rows of a Hyrax commitment dealt out
  *      whole, over several GPUs of ONE process, the partial sums exchanged inside the library: peer copies, host slots, or a
  *      single-process RCCL communicator loaded at run time); reef_merkle_commit_devices (the Merkle tree in blocks over several GPUs); reef_get_device;
@@ -501,10 +502,19 @@ reef_status reef_bench_fmul(int field, uint32_t iters, double *products_per_s);
 typedef struct reef_msm_group reef_msm_group;
 enum { REEF_SPLIT_WINDOWS = 0, REEF_SPLIT_POINTS = 1 };
 enum { REEF_EXCHANGE_DEFAULT = 0, REEF_EXCHANGE_PEER = 1, REEF_EXCHANGE_HOST = 2, REEF_EXCHANGE_RCCL = 3 };
+/* How HOST scalars reach the members of a REEF_SPLIT_WINDOWS group (every member needs ALL of them: 8 x 32 MiB at 2^20 points).
+ * REEF_SCALARS_EACH (default): every member uploads them from the caller's memory over its own PCIe link, all links at once.
+ * REEF_SCALARS_FANOUT: ONE upload to devices[0], then every other member fetches them from there (hipMemcpyPeerAsync on its own stream, after
+ * the upload's event: xGMI, 7 links x ~153 GB/s per GPU against one PCIe link per GPU shared with nothing) -- every member but member 0 goes
+ * through the copy, also one that shares devices[0], so a one-GPU box runs the calls a node runs.  Which of the two wins depends on the host's
+ * PCIe topology and on how much of the caller's memory is pageable; bench.py --single-process reports both.  Ignored for device scalars
+ * (already a fan-out from devices[0]) and for points groups (every member uploads its own slice only). */
+enum { REEF_SCALARS_EACH = 0, REEF_SCALARS_FANOUT = 1 };
 typedef struct {
     uint32_t split;        /* REEF_SPLIT_* */
     uint32_t exchange;     /* REEF_EXCHANGE_* */
-    uint32_t reserved[6];
+    uint32_t scalars;      /* REEF_SCALARS_* */
+    uint32_t reserved[5];
 } reef_msm_group_opts;
 typedef struct {
     uint32_t members;          /* ndev */
@@ -521,6 +531,26 @@ reef_status reef_msm_group_create(reef_msm_group **out, int curve, const reef_af
                                   const reef_msm_group_opts *gopts /* may be NULL: windows, peer */);
 void reef_msm_group_destroy(reef_msm_group *grp);
 reef_status reef_msm_group_info_get(reef_msm_group *grp, reef_msm_group_info *info);
+/* Where the time of a group call goes (diagnostics; round 6: the first run on several physical devices cannot be rehearsed on a one-GPU box, so
+ * one call must be able to say which term is off).  With timing enabled a split call (reef_msm_group_msm, reef_msm_group_rows with rows == 1)
+ * waits for every member separately before the partial sums are added -- a few microseconds of lost overlap -- and records, for the LAST call
+ * (milliseconds, host clock unless said otherwise):
+ *   total_ms         call entry -> result on the host
+ *   distribute_ms    call entry -> every member's share enqueued (the slowest member's issue call: staging of the caller's pageable scalars,
+ *                    peer fetches of device scalars, kernel launches)
+ *   members_done_ms  call entry -> every member's last kernel and the send of its partial sum finished
+ *   combine_ms       from there -> the sum of the partial sums on the host (k_sum_points on devices[0], one wait)
+ *   member_issue_ms[i]   member i's issue call alone
+ *   member_stream_ms[i]  member i's time on its stream, first enqueue to the send of its partial sum (HIP events): its share of the scalars'
+ *                        way to the device, its MSM, its send
+ * members beyond the 16th are not itemised. */
+typedef struct {
+    uint32_t members, reserved;
+    double total_ms, distribute_ms, members_done_ms, combine_ms;
+    double member_issue_ms[16], member_stream_ms[16];
+} reef_msm_group_timing;
+reef_status reef_msm_group_enable_timing(reef_msm_group *grp, int on);
+reef_status reef_msm_group_last_timing(reef_msm_group *grp, reef_msm_group_timing *out);
 /* K1 over the group: out (HOST) = sum_{i<n} scalars[i] * key[i], n <= key length.  scalars: host memory, or device memory of
  * devices[0] (the other devices fetch their share with peer copies). */
 reef_status reef_msm_group_msm(reef_msm_group *grp, const reef_fe *scalars, size_t n, int scalars_loc, bool is_mont, reef_jacobian *out);

@@ -47,12 +47,17 @@ class RuntimeInfo(ctypes.Structure):
 
 
 class GroupOpts(ctypes.Structure):
-    _fields_ = [("split", c_uint32), ("exchange", c_uint32), ("reserved", c_uint32 * 6)]
+    _fields_ = [("split", c_uint32), ("exchange", c_uint32), ("scalars", c_uint32), ("reserved", c_uint32 * 5)]
 
 
 class GroupInfo(ctypes.Structure):
     _fields_ = [("members", c_uint32), ("distinct_devices", c_uint32), ("split", c_uint32), ("exchange", c_uint32), ("peer_members", c_uint32),
                 ("reserved", c_uint32 * 3), ("key_points", c_uint64 * 16)]
+
+
+class GroupTiming(ctypes.Structure):
+    _fields_ = [("members", c_uint32), ("reserved", c_uint32), ("total_ms", c_double), ("distribute_ms", c_double), ("members_done_ms", c_double),
+                ("combine_ms", c_double), ("member_issue_ms", c_double * 16), ("member_stream_ms", c_double * 16)]
 
 
 class KeyCacheTiming(ctypes.Structure):
@@ -136,6 +141,8 @@ def _bind(path: str) -> ctypes.CDLL:
         "reef_msm_group_create": (c_int, [POINTER(vp), c_int, vp, c_size_t, c_int, POINTER(MsmOpts), POINTER(c_int), c_size_t, POINTER(GroupOpts)]),
         "reef_msm_group_destroy": (None, [vp]),
         "reef_msm_group_info_get": (c_int, [vp, POINTER(GroupInfo)]),
+        "reef_msm_group_enable_timing": (c_int, [vp, c_int]),
+        "reef_msm_group_last_timing": (c_int, [vp, POINTER(GroupTiming)]),
         "reef_msm_group_msm": (c_int, [vp, vp, c_size_t, c_int, c_bool, vp]),
         "reef_msm_group_rows": (c_int, [vp, vp, c_size_t, c_size_t, c_int, c_bool, c_uint32, vp, vp, vp]),
         "reef_msm_group_rows_symbols": (c_int, [vp, vp, c_size_t, c_size_t, c_int, c_uint32, vp, vp, c_bool, vp]),

@@ -20,6 +20,7 @@
 #include <thread>
 #include <vector>
 
+#include <chrono>
 #include "common.h"
 
 using namespace reef;
@@ -137,6 +138,8 @@ struct Member {
     size_t stage_cap = 0;
     size_t off = 0, len = 0;            // points split: the slice [off, off + len) of the key
     int rank = 0;                       // RCCL: the member's device as a rank of the group's communicator (member 0's device is rank 0)
+    hipEvent_t t_begin = nullptr, t_end = nullptr;   // timing mode: around the member's share on its stream
+    double issue_ms = 0;                // timing mode: host time of the member's issue call (staging of pageable scalars, peer fetches, launches)
 };
 
 }  // namespace
@@ -152,6 +155,16 @@ struct reef_msm_group {
     std::vector<ncclComm_t> comms;      // RCCL: one communicator handle per distinct device, in order of first appearance in devices[]
     std::vector<size_t> rank_lead;      // RCCL: the first member on each rank's device (its stream carries the rank's sends)
     std::mutex mu;                      // a group serialises its calls
+    // round 6: the first run on several devices cannot be rehearsed, so a call can say where its time went (reef_msm_group_enable_timing)
+    bool timing = false;
+    reef_msm_group_timing last = {};
+    std::chrono::steady_clock::time_point t_call;
+    // round 6: window split from HOST scalars, fan-out variant (reef_msm_group_opts.scalars = REEF_SCALARS_FANOUT): one upload to devices[0], peer copies from there
+    uint32_t scalars_mode = 0;
+    void *fan = nullptr;                // devices[0]: the uploaded scalars
+    size_t fan_cap = 0;
+    hipEvent_t fan_ready = nullptr;     // recorded on member 0's stream after the upload
+    std::atomic<bool> fan_posted{false}; // this call's upload has been enqueued and its event recorded (members spin the microseconds until then)
 };
 
 namespace {
@@ -240,7 +253,33 @@ static reef_status rccl_gather(reef_msm_group *g) {
     return st;
 }
 // All members have enqueued: the partial sums are added on member 0's device and the result is waited for.
+static double ms_between(std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); }
+static reef_status combine_untimed(reef_msm_group *g, reef_jacobian *out);
 static reef_status combine(reef_msm_group *g, reef_jacobian *out) {
+    if (!g->timing) return combine_untimed(g, out);
+    // timing mode: every member is waited for on its own (its events say what its stream spent), then the usual combine
+    reef_status st = REEF_OK;
+    for (auto &mb : g->m) {
+        DeviceGuard dg(mb.device);
+        if (hipEventSynchronize(mb.t_end) != hipSuccess) { (void)hipGetLastError(); set_error("hipEventSynchronize failed on member device %d", mb.device); st = REEF_ERR_HIP; }
+    }
+    g->last.members_done_ms = ms_between(g->t_call, std::chrono::steady_clock::now());
+    for (size_t i = 0; i < g->m.size() && i < 16; ++i) {
+        Member &mb = g->m[i];
+        DeviceGuard dg(mb.device);
+        float ms = 0;
+        if (st == REEF_OK && hipEventElapsedTime(&ms, mb.t_begin, mb.t_end) != hipSuccess) { (void)hipGetLastError(); ms = -1; }
+        g->last.member_stream_ms[i] = ms;
+        g->last.member_issue_ms[i] = mb.issue_ms;
+    }
+    const auto tc = std::chrono::steady_clock::now();
+    if (st == REEF_OK) st = combine_untimed(g, out);
+    const auto te = std::chrono::steady_clock::now();
+    g->last.combine_ms = ms_between(tc, te);
+    g->last.total_ms = ms_between(g->t_call, te);
+    return st;
+}
+static reef_status combine_untimed(reef_msm_group *g, reef_jacobian *out) {
     const size_t nd = g->m.size();
     Member &m0 = g->m[0];
     REEF_ON_DEVICE(m0.device);
@@ -280,11 +319,15 @@ static void group_free(reef_msm_group *g) {
         reef_msm_ctx_destroy(mb.whole);
         reef_msm_ctx_destroy(mb.ctx);
         if (mb.done) (void)hipEventDestroy(mb.done);
+        if (mb.t_begin) (void)hipEventDestroy(mb.t_begin);
+        if (mb.t_end) (void)hipEventDestroy(mb.t_end);
         if (mb.partial) (void)hipFree(mb.partial);
         if (mb.stage) (void)hipFree(mb.stage);
     }
     if (!g->m.empty()) {
         DeviceGuard dg(g->m[0].device);
+        if (g->fan) (void)hipFree(g->fan);
+        if (g->fan_ready) (void)hipEventDestroy(g->fan_ready);
         if (g->gather) {
             if (g->exchange == REEF_EXCHANGE_HOST) (void)hipHostFree(g->gather);
             else (void)hipFree(g->gather);
@@ -320,6 +363,8 @@ reef_status reef_msm_group_create(reef_msm_group **out, int curve, const reef_af
     if (split != REEF_SPLIT_WINDOWS && split != REEF_SPLIT_POINTS) { set_error("reef_msm_group_create: unknown split %u", split); return REEF_ERR_ARG; }
     if (exchange > REEF_EXCHANGE_RCCL) { set_error("reef_msm_group_create: unknown exchange %u", exchange); return REEF_ERR_ARG; }
     if (exchange == REEF_EXCHANGE_DEFAULT) exchange = REEF_EXCHANGE_PEER;
+    const uint32_t scalars_mode = gopts ? gopts->scalars : (uint32_t)REEF_SCALARS_EACH;
+    if (scalars_mode > REEF_SCALARS_FANOUT) { set_error("reef_msm_group_create: unknown scalars mode %u", scalars_mode); return REEF_ERR_ARG; }
     for (size_t i = 0; i < ndev; ++i)
         if (devices[i] < 0) { set_error("reef_msm_group_create: devices[%zu] = %d", i, devices[i]); return REEF_ERR_ARG; }
     const int visible = reef_device_count();
@@ -332,7 +377,7 @@ reef_status reef_msm_group_create(reef_msm_group **out, int curve, const reef_af
     }
     return guarded([&]() -> reef_status {
         reef_msm_group *g = new reef_msm_group();
-        g->curve = curve; g->split = split; g->exchange = exchange; g->n = n;
+        g->curve = curve; g->split = split; g->exchange = exchange; g->n = n; g->scalars_mode = scalars_mode;
         g->m.resize(ndev);
         reef_status st = [&]() -> reef_status {
             const int dev0 = devices[0];
@@ -440,6 +485,27 @@ void reef_msm_group_destroy(reef_msm_group *grp) {
     group_free(grp);
 }
 
+reef_status reef_msm_group_enable_timing(reef_msm_group *grp, int on) {
+    if (!grp) { set_error("null argument"); return REEF_ERR_ARG; }
+    std::lock_guard<std::mutex> lk(grp->mu);
+    if (on)
+        for (auto &mb : grp->m) {
+            if (mb.t_begin) continue;
+            REEF_ON_DEVICE(mb.device);
+            REEF_HIP_TRY(hipEventCreate(&mb.t_begin));
+            REEF_HIP_TRY(hipEventCreate(&mb.t_end));
+        }
+    grp->timing = on != 0;
+    return REEF_OK;
+}
+reef_status reef_msm_group_last_timing(reef_msm_group *grp, reef_msm_group_timing *out) {
+    if (!grp || !out) { set_error("null argument"); return REEF_ERR_ARG; }
+    std::lock_guard<std::mutex> lk(grp->mu);
+    if (!grp->timing || grp->last.members == 0) { set_error("no timed group call yet (reef_msm_group_enable_timing first)"); return REEF_ERR_ARG; }
+    *out = grp->last;
+    return REEF_OK;
+}
+
 reef_status reef_msm_group_info_get(reef_msm_group *grp, reef_msm_group_info *info) {
     if (!grp || !info) { set_error("null argument"); return REEF_ERR_ARG; }
     memset(info, 0, sizeof *info);
@@ -462,17 +528,28 @@ reef_status reef_msm_group_info_get(reef_msm_group *grp, reef_msm_group_info *in
 // One call split over the members: issue(i, target) enqueues member i's share with its partial sum going to `target`.
 static reef_status split_call(reef_msm_group *g, const std::function<reef_status(size_t, reef_jacobian *)> &issue, reef_jacobian *out) {
     Outcome oc;
+    const bool timing = g->timing;
+    if (timing) {
+        memset(&g->last, 0, sizeof g->last);
+        g->last.members = (uint32_t)g->m.size();
+        g->t_call = std::chrono::steady_clock::now();
+    }
     auto one = [&](size_t i) {
         Member &mb = g->m[i];
         DeviceGuard dg(mb.device);
         reef_status st = REEF_OK;
         if (!dg.ok) { set_error("cannot make device %d current: %s", mb.device, hipGetErrorString(dg.err)); st = REEF_ERR_HIP; }
+        const auto t0 = std::chrono::steady_clock::now();
+        if (timing && st == REEF_OK && hipEventRecord(mb.t_begin, mb.stream) != hipSuccess) { set_error("hipEventRecord failed"); st = REEF_ERR_HIP; }
         if (st == REEF_OK) st = issue(i, partial_target(g, i));
         if (st == REEF_OK) st = partial_send(g, i);
+        if (timing && st == REEF_OK && hipEventRecord(mb.t_end, mb.stream) != hipSuccess) { set_error("hipEventRecord failed"); st = REEF_ERR_HIP; }
+        if (timing) mb.issue_ms = ms_between(t0, std::chrono::steady_clock::now());
         oc.note(st);
     };
     if (g->workers) g->workers->run(one);
     else one(0);
+    if (timing) g->last.distribute_ms = ms_between(g->t_call, std::chrono::steady_clock::now());
     if (oc.st != REEF_OK) {                            // whatever was enqueued is waited for before the buffers can be reused
         for (auto &mb : g->m) (void)reef_msm_ctx_sync(mb.ctx);
         return oc.finish();
@@ -484,7 +561,43 @@ extern "C" reef_status reef_msm_group_msm(reef_msm_group *grp, const reef_fe *sc
     if (!grp || !out || (n && !scalars)) { set_error("null argument"); return REEF_ERR_ARG; }
     if (n > grp->n) { set_error("n = %zu exceeds the key length %zu", n, grp->n); return REEF_ERR_ARG; }
     std::lock_guard<std::mutex> lk(grp->mu);
-    return guarded([&] {
+    return guarded([&]() -> reef_status {
+        if (scalars_loc == REEF_HOST && grp->split == REEF_SPLIT_WINDOWS && grp->scalars_mode == REEF_SCALARS_FANOUT && grp->m.size() > 1 && n) {
+            // ONE upload to devices[0] (on member 0's stream), an event, and every other member's peer copy waits for it on its own stream
+            Member &m0 = grp->m[0];
+            const size_t bytes = n * sizeof(reef_fe);
+            {
+                REEF_ON_DEVICE(m0.device);
+                if (bytes > grp->fan_cap) {
+                    if (grp->fan) { (void)hipFree(grp->fan); grp->fan = nullptr; grp->fan_cap = 0; }
+                    REEF_HIP_TRY(hipMalloc(&grp->fan, bytes + bytes / 8 + 256));
+                    grp->fan_cap = bytes + bytes / 8 + 256;
+                }
+                if (!grp->fan_ready) REEF_HIP_TRY(hipEventCreateWithFlags(&grp->fan_ready, hipEventDisableTiming));
+            }
+            const void *fan = grp->fan;
+            grp->fan_posted.store(false, std::memory_order_release);
+            return split_call(grp, [&, fan, bytes](size_t i, reef_jacobian *target) -> reef_status {
+                Member &mb = grp->m[i];
+                const void *src = fan;
+                if (i == 0) {
+                    struct Post {                      // whatever happens to the upload, the other members must not wait for ever (a failed call's result is discarded)
+                        std::atomic<bool> &f;
+                        ~Post() { f.store(true, std::memory_order_release); }
+                    } post{grp->fan_posted};
+                    REEF_HIP_TRY(hipMemcpyAsync(grp->fan, scalars, bytes, hipMemcpyHostToDevice, mb.stream));
+                    REEF_HIP_TRY(hipEventRecord(grp->fan_ready, mb.stream));
+                    grp->fan_posted.store(true, std::memory_order_release);
+                } else {
+                    while (!grp->fan_posted.load(std::memory_order_acquire)) std::this_thread::yield();   // the event must have been RECORDED before it is waited for
+                    REEF_HIP_TRY(hipStreamWaitEvent(mb.stream, grp->fan_ready, 0));
+                    REEF_TRY(member_stage(mb, bytes));
+                    REEF_HIP_TRY(hipMemcpyPeerAsync(mb.stage, mb.device, fan, grp->m[0].device, bytes, mb.stream));   // also for a member on devices[0]: the calls a node runs
+                    src = mb.stage;
+                }
+                return reef_msm(mb.ctx, (const reef_fe *)src, n, REEF_DEVICE, is_mont, target, REEF_DEVICE);
+            }, out);
+        }
         return split_call(grp, [&](size_t i, reef_jacobian *target) -> reef_status {
             Member &mb = grp->m[i];
             size_t off = 0, cnt = n;                   // windows: every member takes all the scalars

@@ -274,6 +274,7 @@ class MsmContext:
 
 
 SPLIT_WINDOWS, SPLIT_POINTS = 0, 1
+SCALARS_EACH, SCALARS_FANOUT = 0, 1      # reef_msm_group_opts.scalars: how host scalars reach the members of a windows group
 EXCHANGE_PEER, EXCHANGE_HOST, EXCHANGE_RCCL = 1, 2, 3
 
 
@@ -283,7 +284,7 @@ class MsmGroup:
     inside the library; on a windows group the rows of a Hyrax commitment are dealt out whole.  `devices` may repeat an ordinal."""
 
     def __init__(self, curve, bases: Buf, devices, n: Optional[int] = None, *, split: int = SPLIT_WINDOWS, exchange: int = 0,
-                 window_bits: int = 0, bucket_groups: int = 1, chunk: int = 0, byte_tables: int = 0):
+                 window_bits: int = 0, bucket_groups: int = 1, chunk: int = 0, byte_tables: int = 0, scalars: int = SCALARS_EACH):
         self.curve = curve_id(curve)
         self._lib = _ffi.load()
         if n is None:
@@ -292,12 +293,23 @@ class MsmGroup:
             n = bases.shape[0]
         loc, ptr = _loc_ptr(bases, 64 * n)
         opts = MsmOpts(window_bits, bucket_groups, chunk, byte_tables, -1, (ctypes.c_uint32 * 3)(0, 0, 0))
-        gopts = _ffi.GroupOpts(split, exchange, (ctypes.c_uint32 * 6)(*([0] * 6)))
+        gopts = _ffi.GroupOpts(split, exchange, scalars, (ctypes.c_uint32 * 5)(*([0] * 5)))
         devs = (ctypes.c_int * len(devices))(*devices)
         h = ctypes.c_void_p()
         check(self._lib.reef_msm_group_create(ctypes.byref(h), self.curve, ptr, n, loc, ctypes.byref(opts), devs, len(devices), ctypes.byref(gopts)))
         self._h = h
         self.n = n
+
+    def enable_timing(self, on: bool = True) -> None:
+        check(self._lib.reef_msm_group_enable_timing(self._h, int(on)))
+
+    def last_timing(self) -> dict:
+        """Where the last split call's time went (reef_msm_group_timing: milliseconds)."""
+        t = _ffi.GroupTiming()
+        check(self._lib.reef_msm_group_last_timing(self._h, ctypes.byref(t)))
+        m = min(t.members, 16)
+        return {"total_ms": t.total_ms, "distribute_ms": t.distribute_ms, "members_done_ms": t.members_done_ms, "combine_ms": t.combine_ms,
+                "member_issue_ms": list(t.member_issue_ms[:m]), "member_stream_ms": list(t.member_stream_ms[:m])}
 
     def info(self) -> dict:
         gi = _ffi.GroupInfo()

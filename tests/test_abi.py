@@ -122,6 +122,9 @@ def test_struct_sizes_of_the_group_api_and_its_argument_errors():
     assert create(nd=0) == 1 and create(nd=65) == 1 and b"members" in lib.reef_last_error()
     assert create(g=ctypes.byref(_ffi.GroupOpts(2, 0))) == 1 and b"split" in lib.reef_last_error()
     assert create(g=ctypes.byref(_ffi.GroupOpts(0, 4))) == 1 and b"exchange" in lib.reef_last_error()
+    assert create(g=ctypes.byref(_ffi.GroupOpts(0, 0, 2))) == 1 and b"scalars" in lib.reef_last_error()          # REEF_SCALARS_*: 0 or 1
+    assert ctypes.sizeof(_ffi.GroupTiming) == 8 + 4 * 8 + 2 * 16 * 8
+    assert lib.reef_msm_group_enable_timing(None, 1) == 1 and lib.reef_msm_group_last_timing(None, None) == 1
     assert create(d=(ctypes.c_int * 2)(0, -1)) == 1
     assert lib.reef_msm_group_create(None, 0, bases.ctypes.data, 4, 0, None, devs, 2, None) == 1
     if lib.reef_device_count() == 0:

@@ -227,3 +227,58 @@ def test_group_rows_at_the_baseline_document_shape_dlog_property(gpu_lib):
         for r in (0, rows // members - 1, rows // members, rows // 2 + 1, rows - 1):         # the edges of the members' blocks
             dl = sum(int(v) * (k0 + j * d) for j, v in enumerate(doc[r].tolist())) % C.order
             assert msm.compress("pallas", got[r].copy()) == C.compress(C.mul(dl, C.gen)), (members, r)
+
+
+@pytest.mark.parametrize("members", [2, 3, 8])
+@pytest.mark.parametrize("exchange", ["peer", "rccl"])
+def test_window_split_scalars_fanned_out_from_member_zero(members, exchange, gpu_lib, cref, key):
+    """Round 6: REEF_SCALARS_FANOUT -- the host scalars of a windows group are uploaded ONCE, to devices[0], and every other member
+    fetches them from there with a peer copy on its own stream after the upload's event (a member on devices[0] too: the calls a node runs).  Same points
+    as the default (every member uploads for itself) and as the oracle; prefixes; repeated calls reuse the staging buffers; device scalars and points
+    groups ignore the option."""
+    from reef_amd import msm
+    cid = 0
+    bases = key[cid]
+    n = bases.shape[0]
+    scs = [cref.gen_scalars(cid, 810 + j, n, kind=j % 2) for j in range(3)]
+    want = [cref.compress(cid, cref.msm_pippenger(cid, bases, s, threads=4)) for s in scs]
+    ex = msm.EXCHANGE_PEER if exchange == "peer" else msm.EXCHANGE_RCCL
+    with msm.MsmGroup(cid, bases, [0] * members, split=msm.SPLIT_WINDOWS, exchange=ex, scalars=msm.SCALARS_FANOUT) as g:
+        for rep in range(2):
+            for j, s in enumerate(scs):
+                assert msm.compress(cid, g.msm(s)) == want[j], (rep, j)
+        for m in (1, members, 999):
+            assert msm.compress(cid, g.msm(scs[0][:m].copy(), m)) == cref.compress(cid, cref.msm_pippenger(cid, bases[:m].copy(), scs[0][:m].copy(), threads=2)), m
+        assert msm.compress(cid, g.msm(np.zeros((0, 4), np.uint64), 0)) == bytes(32)
+        dsc = msm.DeviceBuffer.from_host(scs[1])
+        assert msm.compress(cid, g.msm(dsc, n)) == want[1]
+    with msm.MsmGroup(cid, bases, [0] * members, split=msm.SPLIT_POINTS, scalars=msm.SCALARS_FANOUT) as g:
+        assert msm.compress(cid, g.msm(scs[2])) == want[2]
+
+
+@pytest.mark.parametrize("split", ["windows", "points"])
+def test_group_call_says_where_its_time_went(split, gpu_lib, cref, key):
+    """reef_msm_group_enable_timing / _last_timing: the phases of the last split call -- distribution, the members' streams, the combine -- are
+    reported, are consistent with each other, and the call computes the same point with timing on as off."""
+    from reef_amd import msm
+    cid = 1
+    bases = key[cid]
+    n = bases.shape[0]
+    sc = cref.gen_scalars(cid, 99, n)
+    want = cref.compress(cid, cref.msm_pippenger(cid, bases, sc, threads=4))
+    sp = msm.SPLIT_WINDOWS if split == "windows" else msm.SPLIT_POINTS
+    for scal_mode in (msm.SCALARS_EACH, msm.SCALARS_FANOUT):
+        with msm.MsmGroup(cid, bases, [0, 0, 0], split=sp, scalars=scal_mode) as g:
+            with pytest.raises(msm.ReefError):
+                g.last_timing()                                  # nothing timed yet
+            assert msm.compress(cid, g.msm(sc)) == want
+            g.enable_timing(True)
+            for _ in range(2):
+                assert msm.compress(cid, g.msm(sc)) == want
+            t = g.last_timing()
+            assert len(t["member_issue_ms"]) == 3 and len(t["member_stream_ms"]) == 3
+            assert all(v > 0 for v in t["member_stream_ms"]) and all(v > 0 for v in t["member_issue_ms"])
+            assert 0 < t["distribute_ms"] <= t["members_done_ms"] <= t["total_ms"] and t["combine_ms"] > 0
+            assert t["total_ms"] < 50 and max(t["member_issue_ms"]) <= t["distribute_ms"] + 0.05
+            g.enable_timing(False)
+            assert msm.compress(cid, g.msm(sc)) == want
