@@ -148,6 +148,22 @@ def next_power_of_two(x: int) -> int:
     return 1 if x <= 1 else 1 << (x - 1).bit_length()
 
 
+def merkle_gadget(batch_size: int, doc_len: int) -> int:
+    """NOT in costs.rs (it has no --merkle term): the constraints of NFAStepCircuit::eval_merkle, counted by hand from the gadget itself
+    (src/backend/nova.rs:392-511, merkle_circuit :513-547, select :1404-1429) for `batch_size` document lookups in a tree over `doc_len`
+    symbols (src/backend/merkle_tree.rs:25-78: level 0 hashes PAIRS of (index, symbol), so a path has 1 leaf hash + ceil(log2 doc_len) - 1
+    inner hashes).  Per lookup:
+      leaf      4 selects (one R1CS row each: :1421-1426) + one sponge of [Absorb(4), Squeeze(1)] + ensure_allocated (1 row, :538-542)
+      per level 2 selects + one sponge of [Absorb(2), Squeeze(1)] + ensure_allocated
+      root      1 equality row (:503-508)
+    A sponge is ONE width-5 permutation either way (arity U4: 8 full rounds x 5 S-boxes + 56 partial rounds, x^5 = 3 rows each) = 288 rows --
+    the constant costs.rs itself uses per sponge block (:132).  Allocations (root, the fillers, the l/r bits) add variables, not rows."""
+    sponge = 288 + 1
+    levels = max(1, logmn(next_power_of_two(doc_len)))            # hashes on a path
+    per_lookup = (4 + sponge) + (levels - 1) * (2 + sponge) + 1
+    return batch_size * per_lookup
+
+
 def full_round_cost_model(safa: SafaShape, batch_size: int, doc_len: int, hybrid: bool, hybrid_len: int | None, project: bool) -> int:
     """costs.rs:142-166."""
     dlen_pow2 = next_power_of_two(doc_len)

@@ -79,10 +79,11 @@ def evaluate(cfg: dict) -> dict:
     hybrid_len = 2 * K.next_power_of_two(max(table, udoc_len)) if cfg["hybrid"] else None   # r1cs.rs:481-487
     batch = cfg["batch"] or max(2, K.opt_cost_model_select(safa, udoc_len, cfg["hybrid"], hybrid_len, False, trace))   # r1cs.rs:489-513 (> 1)
     if cfg["merkle"]:
-        # costs.rs has no Merkle term: the document lookups of nl_doc are replaced by b Merkle paths of log2 N Poseidon
-        # hashes each (nova.rs:392-547).  Extrapolated with the model's own sponge-block constant (288, costs.rs:132).
+        # costs.rs has no Merkle term: the document lookups of nl_doc are replaced by b Merkle paths (nova.rs:392-511).  Rounds 1-5 extrapolated b * log2 N * 288;
+        # round 6 counts the gadget's rows by hand (K.merkle_gadget: selects, one width-5 permutation per hash, ensure_allocated, the root equality).  The batch size is
+        # still chosen by costs.rs' model WITHOUT the Merkle term (that is what Reef does: opt_cost_model_select knows nothing of --merkle).
         step = (K.nl(batch, table, False) + K.lookup_idxs(safa.num_states, batch) + K.cursor_circuit(udoc_len, batch, safa.max_offset)
-                + K.stack_circuit(safa.num_states, udoc_len, safa.max_branches, safa.max_stack) + batch * doc_log * 288)
+                + K.stack_circuit(safa.num_states, udoc_len, safa.max_branches, safa.max_stack) + K.merkle_gadget(batch, udoc_len))
     else:
         step = K.full_round_cost_model(safa, batch, udoc_len, cfg["hybrid"], hybrid_len, False)
     steps = K.n_foldings(trace, batch)
@@ -94,6 +95,10 @@ def evaluate(cfg: dict) -> dict:
                merkle_log=doc_log if cfg["merkle"] else 0,
                folded_cost=K.get_folded_cost(step, trace, batch),
                safa_states=sh.num_states, safa_edges=sh.num_edges, safa_max_offsets=sh.max_offsets, solution_lens=trace)
+    if cfg["merkle"]:
+        out["merkle_gadget_constraints"] = K.merkle_gadget(batch, udoc_len)
+        out["merkle_gadget_basis"] = ("hand count of NFAStepCircuit::eval_merkle (src/backend/nova.rs:392-511): per lookup 4 + 289 rows for the leaf, 2 + 289 per inner level "
+                                      f"({doc_log - 1} of them), 1 for the root equality = {K.merkle_gadget(1, udoc_len)} rows; costs.rs has no such term")
     return out
 
 

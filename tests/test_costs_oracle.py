@@ -67,3 +67,20 @@ def test_committed_shapes_are_what_the_model_gives():
     cfg4 = by_name["cfg4_16MiB_dna_hybrid_b32"]
     assert (cfg4["safa_states"], cfg4["safa_edges"], cfg4["solution_lens"], cfg4["steps"]) == (64, 309, [63], 2)     # ceil(63 / 32) folding steps
     assert by_name["cfg4b_16MiB_dna_three_literals_hybrid_b32"]["steps"] == 10
+
+
+def test_merkle_gadget_hand_count():
+    """cfg5's Merkle term (costs.rs has none): the hand count of NFAStepCircuit::eval_merkle (nova.rs:392-511) -- per lookup a leaf hash behind four
+    selects, an inner hash behind two selects per level, one root equality; a hash = one width-5 Poseidon permutation (288 rows, the constant of
+    costs.rs:132) + ensure_allocated."""
+    from oracle import costs_oracle as K
+    assert K.merkle_gadget(1, 2) == 4 + 289 + 1                              # two symbols: the leaf hash is the root
+    assert K.merkle_gadget(1, 4) == (4 + 289) + (2 + 289) + 1
+    assert K.merkle_gadget(1, 1 << 27) == (4 + 289) + 26 * (2 + 289) + 1 == 7860
+    assert K.merkle_gadget(122, (1 << 26) + 2) == 122 * 7860                 # cfg5: 64 MiB + EOF + EPSILON pads to 2^27 symbols
+    assert K.merkle_gadget(3, 5) == 3 * K.merkle_gadget(1, 8)                # ragged documents pay for the padded height
+    import json
+    import os
+    doc = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "replay_shapes.json")))
+    cfg5 = next(s for s in doc["shapes"] if s["name"].startswith("cfg5"))
+    assert cfg5["merkle_gadget_constraints"] == 122 * 7860 and "nova.rs:392-511" in cfg5["merkle_gadget_basis"]

@@ -11,8 +11,22 @@ import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 PIN = os.path.join(ROOT, "tests", "golden", "rust_pin.json")
+# The open debt this skip stands for: every [R] fact of include/reef_msm.h that only the crates can confirm.
+UNCONFIRMED = (
+    "[R1] scalars reach mult_pippenger_* in Montgomery form (is_mont = true)",
+    "[R2] Fp/Fq = 4 x u64 LE limbs, Montgomery R = 2^256; EpAffine 64 B {x, y}, identity (0, 0); Ep 96 B {x, y, z}, identity z = 0",
+    "[R3] GroupEncoding::to_bytes = LE x with the parity of y in bit 255",
+    "[R4] nova-snark dispatches to pasta-msm from 128 points on",
+    "[R5] CommitmentGens::new(label, n): SHAKE256 stream -> hash_to_curve (domain string, SWU / isogeny constants): N1 runs on stand-in parameters",
+    "[R6] neptune's Poseidon constants, MDS orientation and domain tags: N4 runs on stand-in parameters",
+    "[R7] the sponge schedule of linear_mle_product (coefficient order, squeeze -> challenge): N2's vectors are pinned by r1cs.rs:2411-2578, the sponge is not",
+    "[R8] SAFA::new / costs.rs on the replay's regexes (Reef's own code): the restatements are line-for-line but have never met the Rust output",
+)
 if not os.path.exists(PIN):
-    pytest.skip("tests/golden/rust_pin.json absent: run tools/rust_pin on a machine with cargo (tools/rust_pin/README.md)", allow_module_level=True)
+    pytest.skip("tests/golden/rust_pin.json absent -- MSM / N1 / N4 parity stays UNPINNED by the reference.  Three commands on a machine with cargo close it "
+                "(tools/rust_pin/README.md): `cd tools/rust_pin && cargo run --release > ../../tests/golden/rust_pin.json`; `python -m pytest "
+                "tests/test_pin_from_rust.py -q`; `python -m pytest tests/test_pin_from_rust.py -q -m gpu`.  Still unconfirmed: " + "; ".join(UNCONFIRMED),
+                allow_module_level=True)
 
 from oracle.pasta_oracle import CURVES, SplitMix64, ap_bases, sha_hex, uniform_scalar   # noqa: E402
 
