@@ -859,7 +859,7 @@ def main():
         # one is refused rather than quoted (no fall-back to an older round's file)
         traffic, traffic_src = None, None
         from reef_amd import _ffi as _f
-        prof_name = "r05_pmc_traffic.json"
+        prof_name = "r06_pmc_traffic.json"
         try:
             prof = json.load(open(os.path.join(ROOT, "profiles", prof_name)))
             pc = prof["config"]

@@ -18,8 +18,8 @@ def _recorded(name):
 
 
 def test_the_committed_soak_is_of_this_build():
-    assert _recorded("r05_soak.txt") == _ffi.library_sources_sha16(), "the library's sources changed after the soak: soak again (tools/soak.py) and commit it"
+    assert _recorded("r06_soak.txt") == _ffi.library_sources_sha16(), "the library's sources changed after the soak: soak again (tools/soak.py) and commit it"
 
 
 def test_the_committed_stress_run_is_of_this_build():
-    assert _recorded("r05_sc_stress.txt") == _ffi.library_sources_sha16(), "the library's sources changed after the stress run: tools/collect_profiles.sh"
+    assert _recorded("r06_sc_stress.txt") == _ffi.library_sources_sha16(), "the library's sources changed after the stress run: tools/collect_profiles.sh"

@@ -2,7 +2,7 @@
 """Latency probes of the group operations: 256 chained additions / 64 chained doublings on ONE workgroup, four-wave
 forms (ops 7, 8) against the one-wave forms (ops 9, 10); results checked, durations read from a rocprofv3 kernel trace."""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 from oracle import pasta_ref as R
 from oracle.pasta_oracle import CURVES

@@ -5,7 +5,7 @@ import os
 import sys
 import time
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from oracle import pasta_ref as R  # noqa: E402
 
 print("os.cpu_count:", os.cpu_count(), " sched_getaffinity:", len(os.sched_getaffinity(0)))

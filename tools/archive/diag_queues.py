@@ -2,7 +2,7 @@
 """What makes the three concurrent arguments of the replay slow inside a long-lived process?  (bench.py reads 9-10 ms where the
 harness alone reads 6.)  python tools/diag_queues.py"""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from reef_amd import msm, replay
 def rep(tag):

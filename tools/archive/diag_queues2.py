@@ -2,7 +2,7 @@
 """Round 4: which state of a long-lived process slows the three concurrent arguments of the replay (bench.py read 9-10 ms in the
 driver's run where the harness alone reads 6)?  Each mode is one process:  python tools/diag_queues2.py <mode>"""
 import os, sys, threading
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 from reef_amd import msm, replay
 

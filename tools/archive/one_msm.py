@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Run a few MSMs of one size (for rocprofv3 timelines): python tools/one_msm.py logn c G [reps]"""
 import sys, os
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from reef_amd import msm
 logn, c, g = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3])
 reps = int(sys.argv[4]) if len(sys.argv) > 4 else 5

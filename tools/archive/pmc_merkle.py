@@ -13,7 +13,7 @@ import subprocess
 import sys
 from collections import defaultdict
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 LOGN = 24
 LANE_INSTR_PER_S = 34.1e12      # v_mad_u64_u32 chip-wide (profiles/r01_ubench_instruction_rates.txt); the product is MAD-dominated
 res = defaultdict(lambda: defaultdict(list))

@@ -10,7 +10,7 @@ import os
 import subprocess
 import sys
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 ell = sys.argv[1] if len(sys.argv) > 1 else "21"
 ISSUE_WAVE_INSTS_PER_S = 3.27e13 / 64
 d = "/tmp/pmc_sc"

@@ -2,7 +2,7 @@
 """Where the window size should change between 2^15 and 2^19 points (pre-shifted key, one bucket set): latency of ONE MSM in flight (stream time,
 median of 9) and throughput with four in flight, for c = 12..18 at sizes between the powers of two.  python tools/sweep_window_mid.py [n ...]"""
 import os, sys, threading, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 from reef_amd import msm
 

@@ -2,7 +2,7 @@
 """How do latency-bound IPA rounds from several caller threads share the GPU?  N threads, each with its own resident key of
 2^logn generators, each running `rounds` cross-term rounds back to back:   python tools/time_concurrent_ipa.py [logn] [rounds]"""
 import sys, os, time, threading
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from reef_amd import msm
 
 logn = int(sys.argv[1]) if len(sys.argv) > 1 else 15

@@ -7,7 +7,7 @@ import time
 
 import numpy as np
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from reef_amd import msm  # noqa: E402
 
 for logn in [int(x) for x in sys.argv[1:]] or [12, 14, 15, 16, 17, 18]:

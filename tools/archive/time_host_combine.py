@@ -2,7 +2,7 @@
 """Plain (not pre-shifted) keys with the result going to the host: the window combine sum_g 2^(c*g) S_g on a host core
 (default) against the same chain of ~255 doublings on the device (REEF_MSM_HOST_COMBINE=0).  Run once per setting."""
 import os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 from reef_amd import msm
 mode = os.environ.get("REEF_MSM_HOST_COMBINE", "1")

@@ -4,7 +4,7 @@ replace if the sum-check's Fiat-Shamir challenge were squeezed on the device (VE
 leaf hash: one permutation (five lanes per hash below 16384 nodes, a thread per node with REEF_POSEIDON_SPREAD=0); 4 symbols: two
 dependent permutations.  Beside it: what a small sum-check round costs host to host today (launch, kernel, polled result)."""
 import os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import ctypes
 import numpy as np
 from oracle import merkle_oracle as M
