@@ -408,16 +408,29 @@ uint32_t reef_abi_version(void);                       /* REEF_ABI_VERSION of th
  * src/backend/framework.rs:695-721) want 8.  The variable is read at the process's FIRST HIP call, so this must run before it.
  * OPT-IN (ABI 5): the library touches the environment only when asked -- hw_queues > 0 here, or REEF_MSM_HW_QUEUES=<n> exported when
  * the library is loaded; hw_queues < 0 withdraws a value the library set, 0 changes nothing.  A value the user exported as
- * GPU_MAX_HW_QUEUES is never overwritten.  info (may be NULL) reports what the environment holds and who put it there. */
+ * GPU_MAX_HW_QUEUES is never overwritten.  info (may be NULL) reports what the environment holds and who put it there.
+ *
+ * warm (ABI 6): a process's first calls into HIP pay for the runtime, not for the work -- measured on a bare caller of mult_pippenger_pallas
+ * (profiles/r06_seam_hip_first_use.txt): runtime initialisation 51 ms, the first stream 21 ms, the first launch of a code object 7 ms (this library
+ * carries one per curve), the first copy in each direction 8 ms: ~100 ms before the first commitment of a proof whose commitments take 20-30 ms in
+ * all.  Reef spends far longer than that on the host before its first MSM (regex -> SAFA, the step circuit: src/backend/framework.rs:81-166), so the
+ * warm-up can hide behind it: REEF_WARM_BACKGROUND starts a thread of the library that initialises the runtime on the calling thread's CURRENT
+ * device (device 0 for a thread that never chose one), creates the pool's first stream, launches one kernel of each curve's code object and moves a
+ * few bytes host -> device -> host; the call returns at once, and a library call that arrives before the thread has finished simply runs beside it
+ * (HIP's own locks order them).  REEF_WARM_NOW does the same before it returns.  REEF_MSM_WARM=1 in the environment asks for the background form
+ * when the library is LOADED -- the zero-patch route, which has no init call.  info->warm reports 0 (never asked), 1 (running), 2 (done), 3 (failed:
+ * no usable device -- the first real call will say why). */
+enum { REEF_WARM_NONE = 0, REEF_WARM_NOW = 1, REEF_WARM_BACKGROUND = 2 };
 typedef struct {
     int32_t hw_queues;
-    uint32_t reserved[7];
+    uint32_t warm;                     /* REEF_WARM_* */
+    uint32_t reserved[6];
 } reef_runtime_opts;
 typedef struct {
     int32_t hw_queues_env;             /* GPU_MAX_HW_QUEUES as the environment holds it now (0: unset) */
     int32_t hw_queues_set_by_library;  /* the value this library put there (0: it did not) */
     uint32_t abi_version;
-    uint32_t reserved;
+    uint32_t warm;                     /* 0 never asked, 1 running, 2 done, 3 failed */
 } reef_runtime_info;
 reef_status reef_runtime_init(const reef_runtime_opts *opts /* may be NULL */, reef_runtime_info *info /* may be NULL */);
 

@@ -39,11 +39,11 @@ class MsmOpts(ctypes.Structure):
 
 
 class RuntimeOpts(ctypes.Structure):
-    _fields_ = [("hw_queues", c_int32), ("reserved", c_uint32 * 7)]
+    _fields_ = [("hw_queues", c_int32), ("warm", c_uint32), ("reserved", c_uint32 * 6)]
 
 
 class RuntimeInfo(ctypes.Structure):
-    _fields_ = [("hw_queues_env", c_int32), ("hw_queues_set_by_library", c_int32), ("abi_version", c_uint32), ("reserved", c_uint32)]
+    _fields_ = [("hw_queues_env", c_int32), ("hw_queues_set_by_library", c_int32), ("abi_version", c_uint32), ("warm", c_uint32)]
 
 
 class GroupOpts(ctypes.Structure):

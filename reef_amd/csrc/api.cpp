@@ -66,9 +66,16 @@ struct HwQueues {
 // Thread-local destructors of the main thread and static destructors run at process teardown, when HIP may be gone: they look
 // at this flag (set by an atexit hook) and leave the memory to the driver.
 static std::atomic<bool> g_process_exiting{false};
+static std::atomic<int> g_warm_state{0};     // reef_runtime_init's warm-up: 0 never asked, 1 running, 2 done, 3 failed
 static void hook_process_exit() {
     static std::once_flag once;
-    std::call_once(once, [] { atexit([] { g_process_exiting.store(true); }); });
+    std::call_once(once, [] {
+        atexit([] {
+            g_process_exiting.store(true);
+            // a warm-up thread still inside the runtime's initialisation must not meet the runtime's teardown (bounded: it takes ~100 ms)
+            for (int i = 0; i < 4000 && g_warm_state.load() == 1; ++i) std::this_thread::sleep_for(std::chrono::milliseconds(1));
+        });
+    });
 }
 
 static const CurveVTable *vt(int curve) {
@@ -103,6 +110,54 @@ static reef_status require_gpu() {
     if (st != REEF_OK) set_error("%s", msg);
     return st;
 }
+
+// The runtime's one-off costs, paid where nobody waits for them (include/reef_msm.h: reef_runtime_opts.warm): runtime initialisation, the pool's first
+// stream, one launch out of each curve's code object, a copy in each direction from and to pageable memory -- what the first commitment of a process
+// otherwise pays (~100 ms, profiles/r06_seam_hip_first_use.txt).
+static void warm_body() {
+    if (require_gpu() != REEF_OK) { g_warm_state.store(3); return; }
+    reef_fe a[2], b[2], out[2];
+    memset(a, 0, sizeof a);
+    memset(b, 0, sizeof b);
+    a[0].l[0] = 5; a[1].l[0] = 7; b[0].l[0] = 3; b[1].l[0] = 11;
+    bool ok = true;
+    for (int curve = 0; curve < 2; ++curve)      // stage_in (pageable host -> device), a kernel of this curve's code object, device -> pageable host
+        ok = ok && vt(curve)->test_field_op(0, a, b, out, 2) == REEF_OK;
+    // every kernel of the bucket pipeline once per curve (a kernel's first launch resolves it in its code object), the engine's one-off attributes, the first
+    // pinned allocation: a 2048-point MSM over identity points on a plain key, host scalars in, host result out -- and gone again
+    {
+        const size_t n = 2048;
+        std::vector<reef_affine> pts(n);
+        std::vector<reef_fe> sc(n);
+        memset(pts.data(), 0, n * sizeof(reef_affine));                  // (0, 0): the identity
+        for (size_t i = 0; i < n; ++i) { sc[i].l[0] = 0x9e3779b97f4a7c15ull * (i + 1); sc[i].l[1] = i; sc[i].l[2] = ~i; sc[i].l[3] = 0x0123456789abcdefull >> 3; }
+        for (int curve = 0; curve < 2 && ok; ++curve) {
+            PoolNoGrowth ng;
+            reef_msm_ctx *c = nullptr;
+            reef_jacobian out1;
+            ok = reef_msm_ctx_create(&c, curve, pts.data(), n, REEF_HOST, nullptr) == REEF_OK;
+            ok = ok && reef_msm(c, sc.data(), n, REEF_HOST, false, &out1, REEF_HOST) == REEF_OK;
+            reef_msm_ctx_destroy(c);
+        }
+    }
+    g_warm_state.store(ok ? 2 : 3);
+}
+static void start_warm(uint32_t mode) {
+    if (mode == REEF_WARM_NONE) return;
+    int expect = 0;
+    if (!g_warm_state.compare_exchange_strong(expect, 1)) return;     // once per process
+    hook_process_exit();
+    if (mode == REEF_WARM_NOW) { warm_body(); return; }
+    std::thread([] { warm_body(); }).detach();
+}
+namespace {
+struct WarmAtLoad {                                  // the zero-patch route has no init call: REEF_MSM_WARM=1 in the environment asks when the library is loaded
+    WarmAtLoad() {
+        const char *e = getenv("REEF_MSM_WARM");
+        if (e && *e && atoi(e) > 0) start_warm(REEF_WARM_BACKGROUND);   // (its first step is the runtime's own initialisation, tens of ms: the loader has long finished this library's other constructors, the code objects' registration among them)
+    }
+} g_warm_at_load;
+}  // namespace
 
 }  // namespace reef
 
@@ -146,12 +201,16 @@ reef_status reef_runtime_init(const reef_runtime_opts *opts, reef_runtime_info *
         unsetenv("GPU_MAX_HW_QUEUES");               // leave the runtime alone: take the constructor's value back
         g_hw_queues_asked.store(0);
     }
+    if (opts && opts->warm) {
+        if (opts->warm > REEF_WARM_BACKGROUND) { set_error("reef_runtime_init: unknown warm mode %u", opts->warm); return REEF_ERR_ARG; }
+        start_warm(opts->warm);                      // after the hardware queues have been asked for: the warm-up is the process's first HIP call
+    }
     if (info) {
         const char *e = getenv("GPU_MAX_HW_QUEUES");
         info->hw_queues_env = e ? atoi(e) : 0;
         info->hw_queues_set_by_library = g_hw_queues_asked.load();
         info->abi_version = REEF_ABI_VERSION;
-        info->reserved = 0;
+        info->warm = (uint32_t)g_warm_state.load();
     }
     return REEF_OK;
 }

@@ -39,7 +39,8 @@ using clk = std::chrono::steady_clock;
 
 int main(int argc, char **argv) {
     std::vector<long> sizes = {3000, 27790, 65536, 262144}, threads = {1, 4, 8};
-    long calls = 500, reps = 5, first = 0;
+    long calls = 500, reps = 5, first = 0, cold_n = 27790, cold_warm = 0, host_ms = 300;
+    std::string gen_path, cold_path;
     std::vector<long> gaps = {0};
     for (int i = 1; i < argc; ++i) {
         if (!strncmp(argv[i], "sizes=", 6)) sizes = list_of(argv[i] + 6);
@@ -47,8 +48,60 @@ int main(int argc, char **argv) {
         else if (!strncmp(argv[i], "calls=", 6)) calls = atol(argv[i] + 6);
         else if (!strncmp(argv[i], "reps=", 5)) reps = atol(argv[i] + 5);
         else if (!strncmp(argv[i], "first=", 6)) first = atol(argv[i] + 6);
+        else if (!strncmp(argv[i], "gen=", 4)) gen_path = argv[i] + 4;
+        else if (!strncmp(argv[i], "cold=", 5)) cold_path = argv[i] + 5;
+        else if (!strncmp(argv[i], "n=", 2)) cold_n = atol(argv[i] + 2);
+        else if (!strncmp(argv[i], "warm=", 5)) cold_warm = atol(argv[i] + 5);
+        else if (!strncmp(argv[i], "host_ms=", 8)) host_ms = atol(argv[i] + 8);
         else if (!strncmp(argv[i], "gap_us=", 7)) gaps = list_of(argv[i] + 7);
         else { fprintf(stderr, "usage: seam_bench [sizes=a,b] [threads=1,4,8] [calls=500] [reps=5]\n"); return 2; }
+    }
+    if (!gen_path.empty()) {                           // inputs for the cold runs, written by a process of their own
+        std::vector<reef_affine> bases((size_t)cold_n);
+        std::vector<reef_fe> sc((size_t)cold_n);
+        CK(reef_gen_bases(REEF_PALLAS, 4242, 7, (size_t)cold_n, bases.data(), REEF_HOST));
+        CK(reef_gen_scalars(REEF_PALLAS, 77, 0, 0, (size_t)cold_n, true, sc.data(), REEF_HOST));
+        FILE *f = fopen(gen_path.c_str(), "wb");
+        if (!f || fwrite(bases.data(), sizeof(reef_affine), bases.size(), f) != bases.size() || fwrite(sc.data(), sizeof(reef_fe), sc.size(), f) != sc.size()) { fprintf(stderr, "seam_bench: cannot write %s\n", gen_path.c_str()); return 3; }
+        fclose(f);
+        return 0;
+    }
+    if (!cold_path.empty()) {
+        // A FRESH process, as `reef --prove` is: nothing of HIP has run when main() starts.  t = 0 is here.  The prover's own start-up (regex -> SAFA, the
+        // step circuit: hundreds of ms and more on the host, src/backend/framework.rs:81-166) is `host_ms` of sleep; then the first commitments, one by one.
+        // warm: 0 = nothing (the first call pays for the runtime), 2 = reef_runtime_init({warm = REEF_WARM_BACKGROUND}) first thing in main().
+        const auto t_start = clk::now();
+        reef_runtime_opts ro = {};
+        ro.hw_queues = 8;
+        ro.warm = (uint32_t)cold_warm;
+        reef_runtime_info ri = {};
+        (void)reef_runtime_init(&ro, &ri);
+        const double init_ms = std::chrono::duration<double, std::milli>(clk::now() - t_start).count();
+        std::vector<reef_affine> bases((size_t)cold_n);
+        std::vector<reef_fe> sc((size_t)cold_n);
+        FILE *f = fopen(cold_path.c_str(), "rb");
+        if (!f || fread(bases.data(), sizeof(reef_affine), bases.size(), f) != bases.size() || fread(sc.data(), sizeof(reef_fe), sc.size(), f) != sc.size()) { fprintf(stderr, "seam_bench: cannot read %s (write it with gen=)\n", cold_path.c_str()); return 3; }
+        fclose(f);
+        std::this_thread::sleep_for(std::chrono::milliseconds(host_ms));
+        double ms[6];
+        reef_jacobian outs[6];
+        for (int i = 0; i < 6; ++i) {
+            const auto t0 = clk::now();
+            mult_pippenger_pallas(&outs[i], bases.data(), (size_t)cold_n, sc.data(), true);
+            ms[i] = std::chrono::duration<double, std::milli>(clk::now() - t0).count();
+            std::this_thread::sleep_for(std::chrono::milliseconds(1));
+        }
+        (void)reef_runtime_init(nullptr, &ri);
+        reef_affine aff[6];
+        CK(reef_normalize(REEF_PALLAS, outs, 6, REEF_HOST, aff, nullptr));
+        bool same = true;
+        for (int i = 1; i < 6; ++i) same = same && memcmp(&aff[i], &aff[0], sizeof aff[0]) == 0;
+        double sum = 0;
+        for (double v : ms) sum += v;
+        printf("{\"what\": \"a fresh process: the first six commitments\", \"n\": %ld, \"warm\": %ld, \"host_work_before_the_first_call_ms\": %ld, \"reef_runtime_init_ms\": %.3f, "
+               "\"call_ms\": [%.3f, %.3f, %.3f, %.3f, %.3f, %.3f], \"sum_ms\": %.3f, \"warm_state_afterwards\": %u, \"results_identical\": %s}\n",
+               cold_n, cold_warm, host_ms, init_ms, ms[0], ms[1], ms[2], ms[3], ms[4], ms[5], sum, ri.warm, same ? "true" : "false");
+        return same ? 0 : 4;
     }
     {
         reef_runtime_opts ro = {};

@@ -49,6 +49,9 @@ def test_runtime_init_reports_who_set_the_hardware_queues():
     assert info.abi_version == _ffi.ABI_VERSION
     assert info.hw_queues_env == int(os.environ.get("GPU_MAX_HW_QUEUES", "0"))   # reef_amd._ffi (or the user) exported it before the load
     assert info.hw_queues_set_by_library == 0                                  # so the library's constructor left it alone
+    assert info.warm == 0                                                        # nobody asked for the warm-up (REEF_MSM_WARM unset)
+    bad = _ffi.RuntimeOpts(hw_queues=0, warm=3)
+    assert lib.reef_runtime_init(ctypes.byref(bad), None) == 1 and b"warm" in lib.reef_last_error()
     opts = _ffi.RuntimeOpts(hw_queues=16)
     assert lib.reef_runtime_init(ctypes.byref(opts), ctypes.byref(info)) == 0
     assert info.hw_queues_env == int(os.environ.get("GPU_MAX_HW_QUEUES", "0")) and info.hw_queues_set_by_library == 0
