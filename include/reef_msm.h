@@ -506,6 +506,11 @@ reef_status reef_bench_fmul(int field, uint32_t iters, double *products_per_s);
  * chosen.  Every member but member 0 goes through a send/receive pair, also a member that shares member 0's device (a rank
  * sending to itself): a one-GPU box runs the calls an eight-GPU node runs, with other peers.
  *
+ * STATUS: everything in this section has run on ONE physical device only -- groups whose members repeat ordinal 0.  The
+ * branches that need two devices (hipMemcpyPeerAsync between different devices, peer-access enablement, events waited for across devices,
+ * RCCL send/recv between different ranks) are HIP's and RCCL's documented calls and have never executed here: treat the section as
+ * EXPERIMENTAL until it has met a multi-GPU node; reef_msm_group_enable_timing exists so that the first such run explains itself.
+ *
  * devices[] may REPEAT an ordinal: a group of 2 / 3 / 8 members on device 0 runs every code path on a one-GPU box (that is how
  * tests/test_gpu_group.py covers it); members that share a device share the resident key (clones).  Results are identical to
  * reef_msm / reef_msm_rows on one context, whatever the split.  A group serialises the calls made on it.
