@@ -52,6 +52,11 @@ def test_bench_with_two_ranks(sharding, logn, gpu_lib):
         # both combined points checked against the discrete log of the whole MSM (inside cfg["check"])
         ss = cfg["strong_scaling"]
         assert ss["one_msm_points"] == 1 << logn and ss["windows_ms_per_step"] > 0 and ss["points_ms_per_step"] > 0
+        ph = ss["phases"]                                      # round 6: the split itemised per rank beside the model's prediction, so that the first SCALE line explains itself
+        for split in ("windows", "points"):
+            assert len(ph[split]["member_msm_ms"]["per_rank"]) == 2 and ph[split]["member_msm_ms"]["max"] >= ph[split]["member_msm_ms"]["min"] > 0
+            assert ph[split]["exchange_ms"]["max"] > 0
+        assert ph["predicted"]["windows_member_msm_ms"] > 0 and "DESIGN.md 7" in ph["predicted"]["basis"]
         hy = ss["hyrax_rows"]                                  # the row-sharded Hyrax commitment of BASELINE configs[3]
         assert hy["rows"] == 4096 and hy["rows_per_rank"] == 2048 and hy["check"] == "dlog-ok" and hy["ms_per_commit"] > 0
         fs, scs = ss["final_snark"], ss["sumcheck"]            # round 4: whole units over the ranks
@@ -120,6 +125,13 @@ def test_bench_single_process_over_a_device_group(members, logn, exchange, gpu_l
     assert ss["one_msm_points"] == 1 << logn and set(ss["speedup_vs_1"]) == {"windows", "points"}
     for k in ("windows_ms_per_step", "points_ms_per_step", "windows_latency_ms", "points_latency_ms", "one_gpu_ms_per_msm"):
         assert ss[k] > 0, k
+    ph = ss["phases"]                                          # round 6: where one split call's time goes (reef_msm_group_last_timing), both scalar routes
+    for key in ("windows", "windows_fanout_from_member_0", "points"):
+        h = ph[key]["host_scalars"]
+        assert "error" not in ph[key] and h["total_ms"] > 0 and h["scalar_distribution_ms"] > 0 and h["exchange_ms"] > 0
+        assert h["member_msm_ms"]["max"] >= h["member_msm_ms"]["min"] > 0
+    assert ph["windows"]["device_scalars"]["scalar_distribution_ms"] < ph["windows"]["host_scalars"]["scalar_distribution_ms"]
+    assert ph["predicted"]["windows_latency_ms"] > 0
     if logn >= 16:
         assert ss["hyrax_rows"]["check"] == "dlog-ok" and ss["hyrax_rows"]["rows"] == 4096
         assert ss["merkle_commit"]["check"] == "same-root" and ss["merkle_commit"]["blocks"] == {2: 2, 3: 2}[members] and ss["merkle_commit"]["ms_per_commit"] > 0
