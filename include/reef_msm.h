@@ -74,7 +74,7 @@ typedef enum {
  * Stateless: nothing is retained; bases are uploaded per call.  `is_mont` = scalars are in
  * Montgomery form (what the Rust wrapper passes).  abort()s on error.
  * ------------------------------------------------------------------------------------------- */
-/* (A key that keeps coming back is nominated by non-cryptographic hashes of its bytes, CONFIRMED byte for byte
+/* (A key that keeps coming back is nominated by a non-cryptographic hash of 64 sampled points (no pass over all of its bytes), CONFIRMED byte for byte
  * against a retained HOST copy while the GPU already works on the nominated key (helper threads share the comparison of
  * keys above 4 MiB), and served from a resident pre-shifted copy as soon as one exists; a hash collision
  * therefore costs time, never a wrong result, and nothing the caller can observe is retained.  The resident copy is built OFF the

@@ -618,8 +618,7 @@ namespace {
 // call (an epoch), and retries once on the plain, uncached path before the symbol gives up.
 struct SharedKey {
     int curve = 0, device = 0;
-    uint64_t hs = 0;                   // hash of n and 64 sampled points: nominates on the fast path
-    uint64_t hf[2] = {0, 0};           // hash of every byte: identifies the entry on the slow path
+    uint64_t hs = 0;                   // hash of n and 64 sampled points: NOMINATES an entry; only a byte-for-byte comparison confirms it
     size_t n = 0;
     reef_msm_ctx *master = nullptr;    // owns the reference on the pre-shifted tables the threads' contexts share
     void *host_copy = nullptr;         // the bytes the resident key was built from
@@ -755,20 +754,6 @@ static uint64_t sampled_hash(const reef_affine *p, size_t n) {
     take(n - 1);
     return h;
 }
-static void full_hash(const reef_affine *p, size_t n, uint64_t out[2]) {
-    const uint64_t *w = (const uint64_t *)p;
-    const size_t nw = n * 8;
-    uint64_t a[4] = {1, 2, 3, 4}, b[4] = {5, 6, 7, 8};   // four independent chains: the multiplies pipeline
-    for (size_t i = 0; i + 4 <= nw; i += 4)
-        for (int j = 0; j < 4; ++j) {
-            const uint64_t x = w[i + j];
-            a[j] = (a[j] ^ x) * 0x9e3779b97f4a7c15ull + (a[j] >> 29);
-            b[j] = (b[j] + x) * 0xc2b2ae3d27d4eb4full ^ (b[j] >> 31);
-        }
-    out[0] = hmix(a[0]) ^ hmix(a[1] + 1) ^ hmix(a[2] + 2) ^ hmix(a[3] + 3);
-    out[1] = hmix(b[0]) ^ hmix(b[1] + 1) ^ hmix(b[2] + 2) ^ hmix(b[3] + 3) ^ nw;
-}
-
 // A context of the resident path with everything its first call would otherwise have to create: its own workspace, already sized by an
 // MSM of n_warm points, and the host-mapped landing zone the speculative result goes to.
 struct ReadyCtx {
@@ -1044,6 +1029,17 @@ static void schedule_build(const std::shared_ptr<SharedKey> &k, const reef_affin
     k->state.compare_exchange_strong(expect, back_to, std::memory_order_release);
 }
 
+// the caller's bytes against a key's retained copy, without an MSM beside it (choosing among several resident keys that share their samples)
+static bool bytes_equal(const reef_affine *points, const SharedKey &k, size_t bytes) {
+    if (bytes < CMP_PARALLEL_MIN) return memcmp(points, k.host_copy, bytes) == 0;
+    auto job = std::make_shared<CompareJob>();
+    job->a = (const char *)points; job->b = (const char *)k.host_copy; job->bytes = bytes; job->pieces = (bytes + CMP_PIECE - 1) / CMP_PIECE;
+    compare_pool().help(job);
+    job->work();
+    while (!job->finished()) std::this_thread::yield();
+    return job->differ.load() == 0;
+}
+
 // The call on the resident key `k`, speculatively: *same = the caller's bytes are the key's (then *out holds the result).
 static reef_status pippenger_resident(const std::shared_ptr<SharedKey> &k, reef_jacobian *out, const reef_affine *points, size_t npoints,
                                       const reef_fe *scalars, bool is_mont, bool *same) {
@@ -1119,36 +1115,49 @@ static reef_status pippenger_cached(int curve, reef_jacobian *out, const reef_af
     }
     const uint64_t tn = now_ns();
     const uint64_t hs = sampled_hash(points, npoints);
-    std::shared_ptr<SharedKey> k;
-    {                                                  // fast path: the most recently used resident key the samples nominate
+    // Since round 6 the samples are the ONLY hash: rounds 3-5 also hashed every byte of a key that was not (yet) resident -- 0.06 ms per MiB on every such
+    // call, 5 of the 11 ms of a 2^20-point one, and on EVERY call for bases that never return (the IPA's folded generators through the zero-patch route).
+    // Nothing rested on it: a resident key is only ever used after its retained bytes have been compared with the caller's, and a key that is nominated
+    // for a resident copy by its samples alone is built from the bytes of the call that nominates it.
+    std::vector<std::shared_ptr<SharedKey>> cands;     // resident keys the samples nominate, most recently used first
+    {
         std::lock_guard<std::mutex> lk(tab.mu);
         for (auto &e : tab.keys)
-            if (e->curve == curve && e->device == dev && e->n == npoints && e->hs == hs && e->state.load(std::memory_order_acquire) == 2 &&
-                (!k || e->last_use.load() > k->last_use.load()))
-                k = e;
-        if (k) k->last_use.store(++tab.tick);
+            if (e->curve == curve && e->device == dev && e->n == npoints && e->hs == hs && e->state.load(std::memory_order_acquire) == 2) cands.push_back(e);
+        std::sort(cands.begin(), cands.end(), [](const std::shared_ptr<SharedKey> &x, const std::shared_ptr<SharedKey> &y) { return x->last_use.load() > y->last_use.load(); });
+        if (!cands.empty()) cands[0]->last_use.store(++tab.tick);
     }
     g_seam_nominate_ns += now_ns() - tn;
-    if (k) {
+    if (cands.size() == 1) {                           // the usual case: speculate -- the MSM runs while the bytes are compared
         bool same = false;
-        REEF_TRY(pippenger_resident(k, out, points, npoints, scalars, is_mont, &same));
+        REEF_TRY(pippenger_resident(cands[0], out, points, npoints, scalars, is_mont, &same));
         if (same) return REEF_OK;
-        k.reset();                                     // another key with the same samples: the whole content decides
+    } else if (cands.size() > 1) {                     // several resident keys agree on all 64 samples: the bytes choose before any MSM is spent
+        for (auto &c : cands)
+            if (bytes_equal(points, *c, npoints * sizeof(reef_affine))) {
+                {
+                    std::lock_guard<std::mutex> lk(tab.mu);
+                    c->last_use.store(++tab.tick);
+                }
+                bool same = false;
+                REEF_TRY(pippenger_resident(c, out, points, npoints, scalars, is_mont, &same));
+                if (same) return REEF_OK;
+                break;
+            }
     }
-    uint64_t hf[2];
-    full_hash(points, npoints, hf);
+    std::shared_ptr<SharedKey> k;
     bool builder_of = false;
     std::shared_ptr<SharedKey> evicted;                // destroyed after the lock below has been released (declared before it)
     {
         std::lock_guard<std::mutex> lk(tab.mu);
         const uint64_t now = ++tab.tick;
-        for (auto &e : tab.keys)
-            if (e->curve == curve && e->device == dev && e->n == npoints && e->hf[0] == hf[0] && e->hf[1] == hf[1]) k = e;
+        for (auto &e : tab.keys)                       // an entry the samples nominate that has no resident copy (yet)
+            if (e->curve == curve && e->device == dev && e->n == npoints && e->hs == hs && e->state.load() != 2) k = e;
         if (k) {
             k->last_use.store(now);
             k->seen += 1;
             int expect = 0;
-            builder_of = k->seen >= 2 && k->state.compare_exchange_strong(expect, 1);   // second appearance: worth a resident copy
+            builder_of = k->seen >= 2 && k->state.compare_exchange_strong(expect, 1);   // second appearance: worth a resident copy (built from THIS call's bytes)
         } else {
             if (tab.keys.size() >= KEY_TABLE_ENTRIES) {  // forget the least recently used key; keys seen once (no resident copy) go first
                 size_t lru = tab.keys.size();
@@ -1166,18 +1175,13 @@ static reef_status pippenger_cached(int curve, reef_jacobian *out, const reef_af
             }
             if (tab.keys.size() < KEY_TABLE_ENTRIES) {
                 auto e = std::make_shared<SharedKey>();
-                e->curve = curve; e->device = dev; e->n = npoints; e->hs = hs; e->hf[0] = hf[0]; e->hf[1] = hf[1];
+                e->curve = curve; e->device = dev; e->n = npoints; e->hs = hs;
                 e->last_use.store(now);
                 tab.keys.push_back(e);
             }
         }
     }
     evicted.reset();                                   // here: HIP work of the destructor (if this was the last reference) outside the lock
-    if (k && !builder_of && k->state.load(std::memory_order_acquire) == 2) {   // resident, but not what the samples nominated first
-        bool same = false;
-        REEF_TRY(pippenger_resident(k, out, points, npoints, scalars, is_mont, &same));
-        if (same) return REEF_OK;
-    }
     static const bool log_calls = [] { const char *l = getenv("REEF_MSM_LOG"); return l && atoi(l) >= 2; }();
     const uint64_t tp0 = log_calls ? now_ns() : 0;
     const reef_status st = pippenger_plain(curve, out, points, npoints, scalars, is_mont);   // also while the builder is at work on this key
@@ -1187,7 +1191,7 @@ static reef_status pippenger_cached(int curve, reef_jacobian *out, const reef_af
         else { int expect = 1; k->state.compare_exchange_strong(expect, 0); }
     }
     if (log_calls)
-        fprintf(stderr, "libreef_msm: plain-path call (%zu points): nominate + hash %.3f ms, plain MSM %.3f ms, hand-over to the builder %.3f ms\n", npoints, (tp0 - tn) * 1e-6,
+        fprintf(stderr, "libreef_msm: plain-path call (%zu points): nominate %.3f ms, plain MSM %.3f ms, hand-over to the builder %.3f ms\n", npoints, (tp0 - tn) * 1e-6,
                 (tp1 - tp0) * 1e-6, (now_ns() - tp1) * 1e-6);
     return st;
 }
