@@ -61,6 +61,13 @@ int main() {
             CommitmentGensOnDevices<REEF_PALLAS> ckd(gens.data(), n, {0, 0, 0}, &h);
             out += "\"group_commit_blind\": \"" + chex<REEF_PALLAS>(ckd.commit(v.data(), n, blind.data())) + "\", ";
             out += "\"group_commit\": \"" + chex<REEF_PALLAS>(ckd.commit(v.data(), n)) + "\", ";
+            {   // the same key with the host scalars fanned out from devices[0], and the call itemised (round 6)
+                CommitmentGensOnDevices<REEF_PALLAS> ckf(gens.data(), n, {0, 0, 0}, &h, REEF_SPLIT_WINDOWS, REEF_SCALARS_FANOUT);
+                ckf.enable_timing(true);
+                out += "\"group_commit_fanout\": \"" + chex<REEF_PALLAS>(ckf.commit(v.data(), n)) + "\", ";
+                const reef_msm_group_timing t = ckf.last_timing();
+                out += std::string("\"group_timing_consistent\": ") + (t.members == 3 && t.total_ms > 0 && t.distribute_ms <= t.members_done_ms && t.members_done_ms <= t.total_ms ? "true" : "false") + ", ";
+            }
             CommitmentGensOnDevices<REEF_PALLAS> gvd(rg.data(), cols, {0, 0, 0}, &h);
             const auto d1 = gvd.commit_rows(z.data(), rows, cols, bl.data());
             const auto d2 = gvd.commit_symbols(sym.data(), rows, cols, 8, bl.data());

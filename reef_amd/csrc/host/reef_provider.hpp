@@ -138,12 +138,16 @@ template <int CURVE> class CommitmentGens {
 // inside the library), the rows of HyraxPC::commit are dealt out whole.  `devices` may repeat an ordinal.
 template <int CURVE> class CommitmentGensOnDevices {
   public:
-    CommitmentGensOnDevices(const reef_affine *gens, size_t n, const std::vector<int> &devices, const reef_affine *h = nullptr, uint32_t split = REEF_SPLIT_WINDOWS)
+    // scalars: how the caller's host scalars reach the members of a windows group -- every member uploads them over its own PCIe link (REEF_SCALARS_EACH),
+    // or one upload to devices[0] and peer copies from there (REEF_SCALARS_FANOUT); which wins depends on the host's topology (reef_msm.h section 5)
+    CommitmentGensOnDevices(const reef_affine *gens, size_t n, const std::vector<int> &devices, const reef_affine *h = nullptr, uint32_t split = REEF_SPLIT_WINDOWS,
+                            uint32_t scalars = REEF_SCALARS_EACH)
         : n_(n), has_h_(h != nullptr) {
         reef_msm_opts o = {};
         o.bucket_groups = 1;
         reef_msm_group_opts g = {};
         g.split = split;
+        g.scalars = scalars;
         check(reef_msm_group_create(&grp_, CURVE, gens, n, REEF_HOST, &o, devices.data(), devices.size(), &g), "reef_msm_group_create");
         if (h) h_ = *h;
     }
@@ -151,6 +155,13 @@ template <int CURVE> class CommitmentGensOnDevices {
     CommitmentGensOnDevices(const CommitmentGensOnDevices &) = delete;
     CommitmentGensOnDevices &operator=(const CommitmentGensOnDevices &) = delete;
     size_t len() const { return n_; }
+    // where the last commit's time went (distribution of the scalars, every member's stream, the combine): the first run on a real node explains itself
+    void enable_timing(bool on) const { check(reef_msm_group_enable_timing(grp_, on ? 1 : 0), "reef_msm_group_enable_timing"); }
+    reef_msm_group_timing last_timing() const {
+        reef_msm_group_timing t;
+        check(reef_msm_group_last_timing(grp_, &t), "reef_msm_group_last_timing");
+        return t;
+    }
 
     reef_jacobian commit(const reef_fe *v, size_t n, const reef_fe *blind = nullptr) const {
         reef_jacobian out;

@@ -221,6 +221,7 @@ def test_cpp_provider_mirror_matches_oracle(gpu_lib, cref):
     assert got["hyrax"] == want_rows and got["hyrax_symbols"] == want_rows
     # the same through CommitmentGensOnDevices (device groups: three members on device 0)
     assert got["group_commit"] == got["commit"] and got["group_commit_blind"] == got["commit_blind"]
+    assert got["group_commit_fanout"] == got["commit"] and got["group_timing_consistent"] is True      # round 6: REEF_SCALARS_FANOUT and the itemised call through the mirror
     assert got["group_hyrax"] == want_rows and got["group_hyrax_symbols"] == want_rows
     # prove_eval row binding
     zc = [int(x) for x in cref.gen_scalars(0, 11, rows * cols, kind=2, small_bound=131, mont=False)[:, 0]]
