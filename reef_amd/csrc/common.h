@@ -246,9 +246,13 @@ struct StreamPool {
             for (PoolStream *p : streams)
                 if (p->device == device && p->bg_only) return REEF_OK;
         }
-        hipError_t e = hipSuccess;
-        PoolStream *p = make(device, &e);
-        if (!p) { set_error("hipStreamCreate: %s", hipGetErrorString(e)); return REEF_ERR_HIP; }
+        // at the LOWEST priority the device offers: the builder's kernels yield to the callers' wherever the hardware lets them
+        int lo = 0, hi = 0;
+        (void)hipDeviceGetStreamPriorityRange(&lo, &hi);              // lo = the numerically largest = the lowest priority
+        PoolStream *p = new PoolStream();
+        p->device = device;
+        hipError_t e = hipStreamCreateWithPriority(&p->s, hipStreamNonBlocking, lo);
+        if (e != hipSuccess) { delete p; (void)hipGetLastError(); set_error("hipStreamCreate: %s", hipGetErrorString(e)); return REEF_ERR_HIP; }
         p->bg_only = true;
         std::lock_guard<std::mutex> lk(mu);
         streams.push_back(p);
