@@ -20,8 +20,8 @@ def test_design_is_short_enough_to_read():
 
 def test_every_profile_design_cites_exists():
     text = _design()
-    cited = set(re.findall(r"profiles/(r0\d_[A-Za-z0-9_.]+?\.(?:txt|json|jsonl|csv))", text))
-    cited |= {m for m in re.findall(r"`(r0\d_[A-Za-z0-9_]+\.(?:txt|json|jsonl|csv))`", text)}
+    cited = set(re.findall(r"profiles/(r0\d_[A-Za-z0-9_.]+?\.(?:txt|jsonl|json|csv))", text))
+    cited |= {m for m in re.findall(r"`(r0\d_[A-Za-z0-9_]+\.(?:txt|jsonl|json|csv))`", text)}
     assert len(cited) >= 10, cited
     missing = sorted(c for c in cited if not os.path.exists(os.path.join(ROOT, "profiles", c)))
     assert not missing, f"DESIGN.md cites profiles that do not exist: {missing}"
