@@ -174,3 +174,24 @@ def test_replay_library_exports_its_entry_point_and_fails_loudly_without_gpu():
     assert "failed with 3" in str(e.value)
     shapes = replay.shapes()
     assert set(n.split("_")[0] for n in shapes) == {"cfg1", "cfg3", "cfg4", "cfg4b", "cfg5"}
+
+
+def test_warm_up_without_a_gpu_fails_quietly_and_says_so():
+    """REEF_MSM_WARM=1 / reef_runtime_init({warm}) on a box without a usable device: the warm-up thread ends with state 3 (failed), nothing aborts, and the
+    first real call is the one that reports why (no CPU fallback).  A fresh interpreter: the request is read when the library is loaded."""
+    import subprocess
+    import sys
+    code = ("import ctypes, time\n"
+            "from reef_amd import _ffi\n"
+            "lib = _ffi.load(); info = _ffi.RuntimeInfo()\n"
+            "for _ in range(100):\n"
+            "    lib.reef_runtime_init(None, ctypes.byref(info))\n"
+            "    if info.warm != 1: break\n"
+            "    time.sleep(0.1)\n"
+            "print('warm', info.warm, 'devices', lib.reef_device_count())\n")
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120, env=dict(os.environ, REEF_MSM_WARM="1"),
+                         cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    assert out.returncode == 0, out.stderr[-1500:]
+    words = out.stdout.split()
+    state, devices = int(words[1]), int(words[3])
+    assert state == (2 if devices > 0 else 3), out.stdout
