@@ -368,7 +368,11 @@ def test_full_size_dlog_property(name, logn, kind, groups, gpu_lib):
             assert ctx.plan() == {"window_bits": 17, "windows": 16, "bucket_groups": 1, "tables": 16}
         r_dev = ctx.msm(sc_dev, n)            # device-resident scalars
         r_host = ctx.msm(sc)                  # host scalars through the same key
+        d_out = msm.DeviceBuffer(96)          # and the result LEFT ON THE DEVICE (a plain key's window combine then runs as a host function on the stream)
+        ctx.msm(sc_dev, n, out=d_out)
         ctx.sync()
+        r_left = d_out.to_host((12,))
+        d_out.free()
     cols = [canon[:, j].astype(object) for j in range(4)]
     idx = np.arange(n, dtype=object)
     acc = 0
@@ -377,6 +381,7 @@ def test_full_size_dlog_property(name, logn, kind, groups, gpu_lib):
     exp = C.compress(C.mul(acc % C.order, C.gen))
     assert msm.compress(name, r_host) == exp
     assert msm.compress(name, r_dev) == exp
+    assert msm.compress(name, r_left) == exp
     # Montgomery-form input really is the Montgomery image of the canonical one
     assert C.scalar_from_mont(int.from_bytes(sc[12345].tobytes(), "little")) == int.from_bytes(canon[12345].tobytes(), "little")
 
