@@ -1119,67 +1119,81 @@ static reef_status pippenger_cached(int curve, reef_jacobian *out, const reef_af
     // call, 5 of the 11 ms of a 2^20-point one, and on EVERY call for bases that never return (the IPA's folded generators through the zero-patch route).
     // Nothing rested on it: a resident key is only ever used after its retained bytes have been compared with the caller's, and a key that is nominated
     // for a resident copy by its samples alone is built from the bytes of the call that nominates it.
-    std::vector<std::shared_ptr<SharedKey>> cands;     // resident keys the samples nominate, most recently used first
-    {
-        std::lock_guard<std::mutex> lk(tab.mu);
-        for (auto &e : tab.keys)
-            if (e->curve == curve && e->device == dev && e->n == npoints && e->hs == hs && e->state.load(std::memory_order_acquire) == 2) cands.push_back(e);
-        std::sort(cands.begin(), cands.end(), [](const std::shared_ptr<SharedKey> &x, const std::shared_ptr<SharedKey> &y) { return x->last_use.load() > y->last_use.load(); });
-        if (!cands.empty()) cands[0]->last_use.store(++tab.tick);
-    }
-    g_seam_nominate_ns += now_ns() - tn;
-    if (cands.size() == 1) {                           // the usual case: speculate -- the MSM runs while the bytes are compared
-        bool same = false;
-        REEF_TRY(pippenger_resident(cands[0], out, points, npoints, scalars, is_mont, &same));
-        if (same) return REEF_OK;
-    } else if (cands.size() > 1) {                     // several resident keys agree on all 64 samples: the bytes choose before any MSM is spent
-        for (auto &c : cands)
-            if (bytes_equal(points, *c, npoints * sizeof(reef_affine))) {
-                {
-                    std::lock_guard<std::mutex> lk(tab.mu);
-                    c->last_use.store(++tab.tick);
-                }
-                bool same = false;
-                REEF_TRY(pippenger_resident(c, out, points, npoints, scalars, is_mont, &same));
-                if (same) return REEF_OK;
-                break;
-            }
-    }
+    std::vector<std::shared_ptr<SharedKey>> tried;     // resident keys the samples nominated whose bytes turned out to be another key's
     std::shared_ptr<SharedKey> k;
     bool builder_of = false;
-    std::shared_ptr<SharedKey> evicted;                // destroyed after the lock below has been released (declared before it)
-    {
-        std::lock_guard<std::mutex> lk(tab.mu);
-        const uint64_t now = ++tab.tick;
-        for (auto &e : tab.keys)                       // an entry the samples nominate that has no resident copy (yet)
-            if (e->curve == curve && e->device == dev && e->n == npoints && e->hs == hs && e->state.load() != 2) k = e;
-        if (k) {
-            k->last_use.store(now);
-            k->seen += 1;
-            int expect = 0;
-            builder_of = k->seen >= 2 && k->state.compare_exchange_strong(expect, 1);   // second appearance: worth a resident copy (built from THIS call's bytes)
-        } else {
-            if (tab.keys.size() >= KEY_TABLE_ENTRIES) {  // forget the least recently used key; keys seen once (no resident copy) go first
-                size_t lru = tab.keys.size();
-                for (int pass = 0; pass < 2 && lru == tab.keys.size(); ++pass)
-                    for (size_t i = 0; i < tab.keys.size(); ++i) {
-                        const int st = tab.keys[i]->state.load();
-                        if (st == 1 || (pass == 0 && st == 2)) continue;              // never the one being built
-                        if (lru == tab.keys.size() || tab.keys[i]->last_use.load() < tab.keys[lru]->last_use.load()) lru = i;
+    std::shared_ptr<SharedKey> evicted;                // destroyed after the table lock has been released (declared before it is taken)
+    bool first_pass = true;
+    for (;;) {
+        // resident keys the samples nominate and this call has not yet compared itself with, most recently used first.  A LOOP, because the table changes while
+        // a call is outside the lock: a key that another thread's call handed to the builder may be published between this call's look at the table and its turn
+        // to register a (second) appearance -- it must then be compared with, not nominated a second time (two threads that both mis-speculated on a key's twin
+        // while the key itself was being published built it twice: tests/test_gpu_concurrent.py, 3 runs in 8).
+        std::vector<std::shared_ptr<SharedKey>> cands;
+        {
+            std::lock_guard<std::mutex> lk(tab.mu);
+            for (auto &e : tab.keys)
+                if (e->curve == curve && e->device == dev && e->n == npoints && e->hs == hs && e->state.load(std::memory_order_acquire) == 2 &&
+                    std::find(tried.begin(), tried.end(), e) == tried.end())
+                    cands.push_back(e);
+            std::sort(cands.begin(), cands.end(), [](const std::shared_ptr<SharedKey> &x, const std::shared_ptr<SharedKey> &y) { return x->last_use.load() > y->last_use.load(); });
+            if (!cands.empty()) {
+                cands[0]->last_use.store(++tab.tick);
+            } else {
+                // nothing (left) to compare with: register this appearance -- under the SAME lock that found no untried resident key
+                const uint64_t now = ++tab.tick;
+                for (auto &e : tab.keys)               // an entry the samples nominate that has no resident copy (yet)
+                    if (e->curve == curve && e->device == dev && e->n == npoints && e->hs == hs && e->state.load() != 2) k = e;
+                if (k) {
+                    k->last_use.store(now);
+                    k->seen += 1;
+                    int expect = 0;
+                    builder_of = k->seen >= 2 && k->state.compare_exchange_strong(expect, 1);   // second appearance: worth a resident copy (built from THIS call's bytes)
+                } else {
+                    if (tab.keys.size() >= KEY_TABLE_ENTRIES) {  // forget the least recently used key; keys seen once (no resident copy) go first
+                        size_t lru = tab.keys.size();
+                        for (int pass = 0; pass < 2 && lru == tab.keys.size(); ++pass)
+                            for (size_t i = 0; i < tab.keys.size(); ++i) {
+                                const int st = tab.keys[i]->state.load();
+                                if (st == 1 || (pass == 0 && st == 2)) continue;              // never the one being built
+                                if (lru == tab.keys.size() || tab.keys[i]->last_use.load() < tab.keys[lru]->last_use.load()) lru = i;
+                            }
+                        if (lru < tab.keys.size()) {
+                            tab.keys[lru]->state.store(3);
+                            evicted = std::move(tab.keys[lru]);
+                            tab.keys.erase(tab.keys.begin() + lru);
+                        }
                     }
-                if (lru < tab.keys.size()) {
-                    tab.keys[lru]->state.store(3);
-                    evicted = std::move(tab.keys[lru]);
-                    tab.keys.erase(tab.keys.begin() + lru);
+                    if (tab.keys.size() < KEY_TABLE_ENTRIES) {
+                        auto e = std::make_shared<SharedKey>();
+                        e->curve = curve; e->device = dev; e->n = npoints; e->hs = hs;
+                        e->last_use.store(now);
+                        tab.keys.push_back(e);
+                    }
                 }
             }
-            if (tab.keys.size() < KEY_TABLE_ENTRIES) {
-                auto e = std::make_shared<SharedKey>();
-                e->curve = curve; e->device = dev; e->n = npoints; e->hs = hs;
-                e->last_use.store(now);
-                tab.keys.push_back(e);
-            }
         }
+        if (first_pass) g_seam_nominate_ns += now_ns() - tn;
+        if (cands.empty()) break;
+        if (cands.size() == 1 && first_pass) {             // the usual case: speculate -- the MSM runs while the bytes are compared
+            bool same = false;
+            REEF_TRY(pippenger_resident(cands[0], out, points, npoints, scalars, is_mont, &same));
+            if (same) return REEF_OK;
+        } else {                                           // several resident keys agree on all 64 samples (or a late one appeared): the bytes choose before an MSM is spent
+            for (auto &c : cands)
+                if (bytes_equal(points, *c, npoints * sizeof(reef_affine))) {
+                    {
+                        std::lock_guard<std::mutex> lk(tab.mu);
+                        c->last_use.store(++tab.tick);
+                    }
+                    bool same = false;
+                    REEF_TRY(pippenger_resident(c, out, points, npoints, scalars, is_mont, &same));
+                    if (same) return REEF_OK;
+                    break;
+                }
+        }
+        tried.insert(tried.end(), cands.begin(), cands.end());
+        first_pass = false;
     }
     evicted.reset();                                   // here: HIP work of the destructor (if this was the last reference) outside the lock
     static const bool log_calls = [] { const char *l = getenv("REEF_MSM_LOG"); return l && atoi(l) >= 2; }();

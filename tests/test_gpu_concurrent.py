@@ -13,7 +13,10 @@ SIZES = (128, 3000, 27790, 1 << 16)          # below the cache threshold, small,
 
 
 def cache_info():
+    """The table's counters, once the builder thread has nothing left to do: a build an EARLIER test handed over must not land inside the window of the test that
+    reads a delta (round 6: builds are asynchronous)."""
     from reef_amd import _ffi
+    _ffi.load().reef_key_cache_wait()
     st = _ffi.KeyCacheStats()
     _ffi.load().reef_key_cache_info(ctypes.byref(st))
     return {n: getattr(st, n) for n, _ in st._fields_}
