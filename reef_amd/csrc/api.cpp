@@ -605,13 +605,14 @@ namespace {
 // prepares a spare context whose workspace has already served a (zero-scalar) MSM of the key's length, with its host-mapped landing zone.
 // The first call that finds the key published takes that spare instead of creating a context.  Until then calls keep to the plain path:
 // a caller never waits for the builder thread (its kernels are ordered among the caller's own on the shared stream: one call waits the 1-2 ms of
-// GPU time the tables take).  The builder also destroys the contexts threads let go of.
+// GPU time the tables take).  The builder also keeps the contexts threads let go of as spares (a pool of three per curve; destroying one
+// beside a busy caller is thirty hipFree waits), each still holding its key until it is attached elsewhere or destroyed.
 //
 // The table of resident keys is ONE per process (nova-snark reaches this symbol from the prover thread and from rayon workers,
 // src/backend/framework.rs:110,668,695): a key is built once, and every caller thread serves it through a context of its own attached
 // to the key of the moment (reef_msm_ctx_attach: O(1)).  The table lock is held for lookups only, NEVER across HIP work or a destructor
 // that does HIP work: entries that leave the table are destroyed after the lock is released, and an entry lives on --
-// charged to the budget -- until the last thread whose context is attached to it has moved on or ended.  Device memory is charged to one
+// charged to the budget -- until the last context attached to it (a thread's, or a pooled spare) has moved on or ended.  Device memory is charged to one
 // budget (REEF_MSM_KEY_CACHE_MB, default 16384), the host copies to another (REEF_MSM_KEY_HOST_MB, default 4096), both RESERVED
 // atomically before anything is allocated; a key that finds a budget full goes back to "nominated" and is tried again when it
 // returns.  An allocation failure anywhere on this path empties the table, tells every thread to let go of its attachment at its next
@@ -761,14 +762,19 @@ struct ReadyCtx {
     reef_jacobian *pinned = nullptr;
     int device = -1;
     size_t n_warm = 0;
+    std::shared_ptr<SharedKey> key;                    // the key ctx is attached to: it (and its share of the budget) lives while any context -- a thread's or a pooled one -- is on its tables
     void destroy() {                                   // HIP work: on the builder thread, or where nobody is waiting
         reef_msm_ctx_destroy(ctx);
         if (pinned) (void)hipHostFree(pinned);
         ctx = nullptr; pinned = nullptr; device = -1; n_warm = 0;
+        key.reset();                                   // after the context: the key's destructor frees what the context was reading
     }
 };
-static reef_status ready_ctx_make(ReadyCtx *r, reef_msm_ctx *master, int device, size_t n_warm) {
+static reef_status ready_ctx_make(ReadyCtx *r, const std::shared_ptr<SharedKey> &k, size_t n_warm) {
+    reef_msm_ctx *master = k->master;
+    const int device = k->device;
     r->device = device;
+    r->key = k;
     {
         PoolNoGrowth ng;
         REEF_TRY(reef_msm_ctx_clone(&r->ctx, master));
@@ -792,11 +798,12 @@ static reef_status ready_ctx_make(ReadyCtx *r, reef_msm_ctx *master, int device,
 }
 
 // ONE helper thread per process, started by the first call that has work for it.  Jobs: make sure the pool has streams to hand out (PREPARE),
-// build a key's resident copy and a spare context for it (BUILD), destroy a context a thread let go of (RETIRE).  Callers only ever push
+// build a key's resident copy and a spare context for it (BUILD), pool a context a thread let go of (RETIRE), destroy the pooled ones of a key
+// that left the table (PURGE).  Callers only ever push
 // and take; they never wait for a job.  At process exit the atexit hook below lets the job in flight finish and drops the rest -- no HIP
 // call of this thread may overlap the runtime's teardown.
 struct Builder {
-    enum Kind { PREPARE, BUILD, RETIRE };
+    enum Kind { PREPARE, BUILD, RETIRE, PURGE };
     struct Job {
         Kind kind = PREPARE;
         int device = 0;
@@ -808,7 +815,8 @@ struct Builder {
     std::condition_variable cv, idle_cv;
     std::deque<Job> q;
     bool started = false, busy = false;
-    std::vector<ReadyCtx> spares[2];                   // per curve, under mu: at most one per device
+    std::vector<ReadyCtx> spares[2];                   // per curve, under mu: ready contexts nobody is using (the builder's fresh ones and the ones threads let go of)
+    static constexpr size_t SPARES_MAX = 3;            // per curve; one more and the smallest is destroyed
     std::atomic<uint64_t> jobs_done{0};
 
     void push(Job &&j) {
@@ -826,13 +834,31 @@ struct Builder {
     bool take(int curve, int device, size_t n, ReadyCtx *out) {
         std::lock_guard<std::mutex> lk(mu);
         auto &v = spares[curve];
+        size_t best = v.size();
         for (size_t i = 0; i < v.size(); ++i)
-            if (v[i].device == device && v[i].n_warm >= n) {
-                *out = v[i];
-                v.erase(v.begin() + i);
-                return true;
-            }
-        return false;
+            if (v[i].device == device && v[i].n_warm >= n && (best == v.size() || v[i].n_warm < v[best].n_warm)) best = i;
+        if (best == v.size()) return false;
+        *out = v[best];
+        v.erase(v.begin() + best);
+        return true;
+    }
+    // A context joins the spares.  Contexts are KEPT rather than destroyed: destroying one is ~30 hipFree calls, each of which waits for the device -- beside a
+    // caller that keeps the GPU busy that took 30 ms and stretched the caller's calls from 0.9 to 3.6 ms meanwhile (profiles/r06_stateless_pcie_inclusive.txt,
+    // the 2^18 row of the first collections).  Returns the context to destroy when the pool is full: the one with the smallest workspace.
+    ReadyCtx give(int curve, const ReadyCtx &r) {
+        std::lock_guard<std::mutex> lk(mu);
+        // a context on the tables of a key that left the table is not kept: it would keep them, and their share of the budget, alive.  (Under mu: clear() marks the keys
+        // BEFORE take_all() takes this lock, an eviction BEFORE its PURGE job is pushed -- a context that slips in here is found by either.)
+        if (r.key && r.key->state.load() == 3) return r;
+        auto &v = spares[curve];
+        v.push_back(r);
+        if (v.size() <= SPARES_MAX) return ReadyCtx();
+        size_t small = 0;
+        for (size_t i = 1; i < v.size(); ++i)
+            if (v[i].n_warm < v[small].n_warm) small = i;
+        const ReadyCtx victim = v[small];
+        v.erase(v.begin() + small);
+        return victim;
     }
     // every spare leaves (the table was emptied: their clones hold references on the keys' tables); destroyed by the caller
     std::vector<ReadyCtx> take_all() {
@@ -888,7 +914,7 @@ struct Builder {
             }
             jobs_done += 1;
             if (log_jobs)
-                fprintf(stderr, "libreef_msm: builder job %s (%zu points) took %.3f ms, ended at %.3f ms\n", kind == PREPARE ? "PREPARE" : kind == BUILD ? "BUILD" : "RETIRE", npts,
+                fprintf(stderr, "libreef_msm: builder job %s (%zu points) took %.3f ms, ended at %.3f ms\n", kind == PREPARE ? "PREPARE" : kind == BUILD ? "BUILD" : kind == RETIRE ? "RETIRE" : "PURGE", npts,
                         (now_ns() - tj) * 1e-6, (now_ns() % 100000000000ull) * 1e-6);
             {
                 std::lock_guard<std::mutex> lk(mu);
@@ -906,7 +932,23 @@ struct Builder {
         j.key->state.compare_exchange_strong(expect, state, std::memory_order_release);
     }
     void execute(Job &j) {
-        if (j.kind == RETIRE) { j.retire.destroy(); return; }
+        if (j.kind == RETIRE) {                        // kept as a spare; only a full pool costs a destruction
+            ReadyCtx victim = give(j.device, j.retire);
+            victim.destroy();
+            return;
+        }
+        if (j.kind == PURGE) {                         // a key left the table: pooled contexts still on its tables would keep them (and their share of the budget) alive
+            std::vector<ReadyCtx> gone;
+            {
+                std::lock_guard<std::mutex> lk(mu);
+                for (auto &v : spares)
+                    for (size_t i = 0; i < v.size();)
+                        if (v[i].key && v[i].key->state.load() == 3) { gone.push_back(v[i]); v.erase(v.begin() + i); }
+                        else ++i;
+            }
+            for (auto &r : gone) r.destroy();
+            return;
+        }
         DeviceGuard dg(j.device);
         if (!dg.ok) { if (j.kind == BUILD) fail_build(j, 4); return; }
         if (j.kind == PREPARE) return;                 // (kept for embedders' diagnostics; nothing to prepare since the pool no longer grows here)
@@ -920,20 +962,17 @@ struct Builder {
         o.device = k.device;
         reef_msm_ctx *master = nullptr;
         if (reef_msm_ctx_create(&master, k.curve, (const reef_affine *)j.copy, k.n, REEF_HOST, &o) != REEF_OK) { fail_build(j, 4); return; }
-        ReadyCtx spare;
-        if (ready_ctx_make(&spare, master, k.device, k.n) != REEF_OK) spare.destroy();      // never fatal: the first caller makes its own
         k.host_copy = j.copy;
-        k.master = master;
+        k.master = master;                             // (nobody reads it before state 2)
         j.copy = nullptr;
+        ReadyCtx spare;
+        if (ready_ctx_make(&spare, j.key, k.n) != REEF_OK) spare.destroy();      // never fatal: the first caller makes its own
         g_cache_builds += 1;
         ReadyCtx old;
         if (spare.ctx) {                               // BEFORE the key is published: whoever sees state 2 finds the spare
-            std::lock_guard<std::mutex> lk(mu);
-            auto &v = spares[k.curve];
-            for (size_t i = 0; i < v.size(); ++i)
-                if (v[i].device == k.device) { old = v[i]; v.erase(v.begin() + i); break; }
-            v.push_back(spare);
+            old = give(k.curve, spare);
             g_cache_spares += 1;
+            if (old.ctx == spare.ctx) { spare.destroy(); old = ReadyCtx(); }      // (the pool was full of larger ones, any of which serves this key: the new spare itself goes)
         }
         int expect = 1;                                // an entry evicted meanwhile (state 3) stays evicted; its destructor frees what was built
         if (!k.state.compare_exchange_strong(expect, 2, std::memory_order_release) && spare.ctx) {
@@ -946,7 +985,7 @@ struct Builder {
             }
             if (mine) spare.destroy();
         }
-        if (old.ctx) old.destroy();                    // the previous key's spare nobody took
+        if (old.ctx) old.destroy();                    // the pool was full: its smallest context goes
     }
 };
 Builder &Builder::builder_instance() {
@@ -969,19 +1008,22 @@ void KeyTable::clear() {
 struct TlsCtx {
     reef_msm_ctx *ctx[2] = {nullptr, nullptr};      // plain path: re-keyed on every call
     ReadyCtx r[2];                                  // resident path: this thread's stream, workspace and landing zone, attached to whichever shared key a call nominates
-    std::shared_ptr<SharedKey> attached[2];         // the key r[c] is attached to: it (and its share of the budget) lives while any thread's context is on its tables
     int ctx_dev[2] = {-1, -1};
     uint64_t epoch = 0;
     void drop_resident() {
-        for (int c = 0; c < 2; ++c) {
-            r[c].destroy();
-            attached[c].reset();                       // after the context: the key's destructor frees what the context was reading
-        }
+        for (int c = 0; c < 2; ++c) r[c].destroy();
     }
     ~TlsCtx() {
         if (g_process_exiting.load()) return;          // process teardown: never call into HIP (the keys' destructors look at the same flag)
         for (auto *c : ctx) reef_msm_ctx_destroy(c);
-        drop_resident();
+        for (int c = 0; c < 2; ++c) {                  // a worker thread that ends hands its resident contexts to the pool: the next worker takes them as they are
+            if (r[c].ctx) {
+                Builder::Job j;
+                j.kind = Builder::RETIRE; j.retire = r[c]; j.device = c;
+                r[c] = ReadyCtx();
+                builder().push(std::move(j));
+            }
+        }
     }
 };
 thread_local TlsCtx g_tls;
@@ -1048,9 +1090,8 @@ static reef_status pippenger_resident(const std::shared_ptr<SharedKey> &k, reef_
     ReadyCtx &r = g_tls.r[curve];
     auto retire = [&] {                                // destroyed by the builder thread, not here
         Builder::Job j;
-        j.kind = Builder::RETIRE; j.retire = r;
-        r = ReadyCtx();
-        g_tls.attached[curve].reset();                 // (the retired context still holds its reference on the key's tables until it is destroyed)
+        j.kind = Builder::RETIRE; j.retire = r; j.device = curve;      // (for a RETIRE job `device` carries the curve: the pool is per curve)
+        r = ReadyCtx();                                // (the retired context keeps its key -- tables and budget -- until it is attached elsewhere or destroyed)
         builder().push(std::move(j));
     };
     if (r.ctx && r.device != k->device) retire();
@@ -1062,12 +1103,12 @@ static reef_status pippenger_resident(const std::shared_ptr<SharedKey> &k, reef_
         }
     }
     if (!r.ctx) {                                      // no spare (another thread took it): this thread makes its own
-        const reef_status st = ready_ctx_make(&r, k->master, k->device, 0);
+        const reef_status st = ready_ctx_make(&r, k, 0);
         if (st != REEF_OK) { r.destroy(); return st; }
         g_cache_clones += 1;
     }
-    if (g_tls.attached[curve] != k) REEF_TRY(reef_msm_ctx_attach(r.ctx, k->master));   // O(1): the thread's stream and workspace on another key's tables
-    g_tls.attached[curve] = k;                         // the key this thread let go of may end here (its last reference): outside every lock
+    if (r.key != k) REEF_TRY(reef_msm_ctx_attach(r.ctx, k->master));   // O(1): the thread's stream and workspace on another key's tables
+    r.key = k;                                         // the key this context let go of may end here (its last reference): outside every lock
     reef_msm_ctx *c = r.ctx;
     const uint64_t t0 = now_ns();
     std::shared_ptr<CompareJob> job;
@@ -1194,6 +1235,11 @@ static reef_status pippenger_cached(int curve, reef_jacobian *out, const reef_af
         }
         tried.insert(tried.end(), cands.begin(), cands.end());
         first_pass = false;
+    }
+    if (evicted) {                                     // pooled contexts still attached to it are destroyed by the builder thread
+        Builder::Job j;
+        j.kind = Builder::PURGE;
+        builder().push(std::move(j));
     }
     evicted.reset();                                   // here: HIP work of the destructor (if this was the last reference) outside the lock
     static const bool log_calls = [] { const char *l = getenv("REEF_MSM_LOG"); return l && atoi(l) >= 2; }();

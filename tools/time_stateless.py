@@ -38,11 +38,18 @@ if not args.threads:
             msm.mult_pippenger("pallas", bases, sc)
             first.append((time.perf_counter() - t0) * 1e3)
         _ffi.load().reef_key_cache_wait()              # the steady state below is the resident key's (the first calls one by one: seam_bench first=1)
+        msm.mult_pippenger("pallas", bases, sc)        # the first hit takes the builder's spare context: not part of the steady state either
+        tm = _ffi.KeyCacheTiming()
+        _ffi.load().reef_key_cache_timing_get(None, 1)
         t0 = time.perf_counter()
         reps = 10
         for _ in range(reps):
             msm.mult_pippenger("pallas", bases, sc)
         dt = (time.perf_counter() - t0) / reps
+        _ffi.load().reef_key_cache_timing_get(ctypes.byref(tm), 0)
+        if os.environ.get("REEF_MSM_LOG") == "2" and tm.calls:
+            print(f"    host time per steady call (us): nominate {tm.nominate_ns/tm.calls/1e3:.1f} enqueue {tm.enqueue_ns/tm.calls/1e3:.1f} confirm {tm.confirm_ns/tm.calls/1e3:.1f} "
+                  f"wait {tm.wait_ns/tm.calls/1e3:.1f} ({tm.calls} calls)", file=sys.stderr)
         print(f"mult_pippenger_pallas n=2^{logn}: calls 1-3 {first[0]:.2f} / {first[1]:.2f} / {first[2]:.2f} ms, then {dt*1e3:.3f} ms "
               f"= {n/dt/1e6:.1f} Mpairs/s (PCIe-inclusive, {96*n/dt/1e9:.2f} GB/s of host input)", flush=True)
     sys.exit(0)
