@@ -140,6 +140,9 @@ static void warm_body() {
             reef_msm_ctx_destroy(c);
         }
     }
+    // the builder thread's own stream (keys of 2^17 points and more are built there, common.h): its creation is 7-9 ms of the first such key's build otherwise
+    int dev = 0;
+    if (ok && hipGetDevice(&dev) == hipSuccess) (void)stream_pool().ensure_background_stream(dev);
     g_warm_state.store(ok ? 2 : 3);
 }
 static void start_warm(uint32_t mode) {
@@ -797,15 +800,14 @@ static reef_status ready_ctx_make(ReadyCtx *r, const std::shared_ptr<SharedKey> 
     return REEF_OK;
 }
 
-// ONE helper thread per process, started by the first call that has work for it.  Jobs: make sure the pool has streams to hand out (PREPARE),
-// build a key's resident copy and a spare context for it (BUILD), pool a context a thread let go of (RETIRE), destroy the pooled ones of a key
-// that left the table (PURGE).  Callers only ever push
-// and take; they never wait for a job.  At process exit the atexit hook below lets the job in flight finish and drops the rest -- no HIP
-// call of this thread may overlap the runtime's teardown.
+// ONE helper thread per process, started by the first call that has work for it.  Jobs: build a key's resident copy and a spare context for it
+// (BUILD), pool a context a thread let go of (RETIRE), destroy the pooled ones of a key that left the table (PURGE).  Callers only ever push and
+// take; they never wait for a job.  At process exit the atexit hook below lets the job in flight finish and drops the rest -- no HIP call of
+// this thread may overlap the runtime's teardown.
 struct Builder {
-    enum Kind { PREPARE, BUILD, RETIRE, PURGE };
+    enum Kind { BUILD, RETIRE, PURGE };
     struct Job {
-        Kind kind = PREPARE;
+        Kind kind = BUILD;
         int device = 0;
         std::shared_ptr<SharedKey> key;
         void *copy = nullptr;
@@ -914,7 +916,7 @@ struct Builder {
             }
             jobs_done += 1;
             if (log_jobs)
-                fprintf(stderr, "libreef_msm: builder job %s (%zu points) took %.3f ms, ended at %.3f ms\n", kind == PREPARE ? "PREPARE" : kind == BUILD ? "BUILD" : kind == RETIRE ? "RETIRE" : "PURGE", npts,
+                fprintf(stderr, "libreef_msm: builder job %s (%zu points) took %.3f ms, ended at %.3f ms\n", kind == BUILD ? "BUILD" : kind == RETIRE ? "RETIRE" : "PURGE", npts,
                         (now_ns() - tj) * 1e-6, (now_ns() % 100000000000ull) * 1e-6);
             {
                 std::lock_guard<std::mutex> lk(mu);
@@ -951,7 +953,6 @@ struct Builder {
         }
         DeviceGuard dg(j.device);
         if (!dg.ok) { if (j.kind == BUILD) fail_build(j, 4); return; }
-        if (j.kind == PREPARE) return;                 // (kept for embedders' diagnostics; nothing to prepare since the pool no longer grows here)
         SharedKey &k = *j.key;
         // a long build gets (once per process and device) a stream of this thread's own: on a caller's stream its kernels would keep that
         // caller's next call waiting for the whole build; short ones are not worth a stream creation (common.h)

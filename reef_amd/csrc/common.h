@@ -36,8 +36,9 @@ void set_error(const char *fmt, ...) __attribute__((format(printf, 1, 2)));
 // ("Environment"): REEF_MSM_KEY_CACHE, REEF_MSM_KEY_CACHE_MB, REEF_MSM_KEY_HOST_MB, REEF_MSM_CMP_THREADS, REEF_MSM_STREAMS, REEF_MSM_HW_QUEUES,
 // REEF_MSM_LOG, REEF_MSM_WIDE, REEF_MSM_WIDE_MAX_LOG, REEF_MSM_HOST_COMBINE, REEF_MSM_GRAPH, REEF_MSM_WARM, REEF_SC_FENCE, REEF_RCCL_LIB -- read with getenv.  EXPERIMENTAL ones exist
 // for A/B measurements (tools/, profiles/) and for tests that force a code path at sizes the oracle can handle; they are read through
-// exp_env and exist only in builds with -DREEF_EXPERIMENT (the in-tree build: csrc/Makefile, EXPERIMENT=1).  `make release` builds
-// libreef_msm_release.so without them: there an undocumented variable in the environment changes nothing.
+// exp_env and exist only in builds with -DREEF_EXPERIMENT: libreef_msm_exp.so (csrc/Makefile), which a few tests and tools/ load on request.
+// libreef_msm.so -- what ships, what the GPU suite tests and bench.py measures -- is built without it: there an undocumented variable in the
+// environment changes nothing.
 inline const char *exp_env(const char *name) {
 #ifdef REEF_EXPERIMENT
     return getenv(name);

@@ -198,6 +198,8 @@ def test_table_turnover_under_concurrency(gpu_lib, cref):
     keys = [cref.gen_bases_ap(cid, 4000 + 17 * k, 5, n) for k in range(20)]
     sc = cref.gen_scalars(cid, 77, n)
     want = [cref.compress(cid, cref.msm_pippenger(cid, kb, sc, threads=4)) for kb in keys]
+    gpu_lib.reef_key_cache_clear()
+    base = cache_info()["resident_bytes"]           # what this (the main) thread's own attachments pin: it makes no call until the end
 
     def work(t):
         for rnd in range(3):
@@ -208,6 +210,14 @@ def test_table_turnover_under_concurrency(gpu_lib, cref):
     info = cache_info()
     assert info["entries"] <= 16 and info["resident_keys"] <= 16
     gpu_lib.reef_key_cache_clear()
+    # the workers have ended: their contexts went to the builder's pool WITH the keys they were attached to, and pooled contexts of keys that left
+    # the table are destroyed (round 6) -- nothing but the main thread's own attachments may stay charged
+    import time
+    for _ in range(300):                            # Thread.join() returns before the native thread has run its thread-local destructors
+        if cache_info()["resident_bytes"] == base:
+            break
+        time.sleep(0.01)                            # (a context that reaches the builder after the clear is not pooled: its key has left the table)
+    assert cache_info()["resident_bytes"] == base
     msm.mult_pippenger(cid, keys[0], sc)            # this thread lets go of the clones it holds of evicted keys
     assert cache_info()["entries"] == 1
 
