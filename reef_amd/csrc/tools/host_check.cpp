@@ -4,9 +4,12 @@
 // (libreef_msm.so) never links this.
 //   g++ -O2 -std=c++17 -DREEF_BOUNDS -shared -fPIC host_check.cpp -o libreef_hostcheck.so
 #include <string.h>
+#include <vector>
 
 #include "../ec.h"
 #include "../glv_host.h"
+#include "../host_combine.h"
+#include <chrono>
 
 using namespace reef;
 
@@ -61,7 +64,37 @@ template <int C> static void accumulate(const affine256 *pts, const uint8_t *neg
     *out_comp = affine_compress<C>(a);
 }
 
+// The window combine of a plain key (host_combine.h) against ec.h's own chain.  pts holds two ABI affine points per window; the window's
+// sum is their sum (either or both may be the identity (0, 0)), built with the kernels' mixed addition and sent through the engine's memory
+// form -- un-normalised limbs and all -- as the landing zone holds it.  Returns the microseconds of (new, old) per combine.
+template <int C> static void window_combine(const affine256 *pts, u32 G, u32 c, jacobian256 *out_new, jacobian256 *out_old, double *us_new, double *us_old) {
+    std::vector<xyzz_mem> gs(G);
+    for (u32 g = 0; g < G; ++g) {
+        xyzz s = xyzz_madd_flag<C>(xyzz_identity(), true, affine_from_abi<C>(pts[2 * g]));
+        s = xyzz_madd<C>(s, affine_from_abi<C>(pts[2 * g + 1]));
+        gs[g] = xyzz_to_mem(s);
+    }
+    const int reps = 5;
+    auto t0 = std::chrono::steady_clock::now();
+    for (int r = 0; r < reps; ++r) *out_new = host_window_combine<C>(gs.data(), G, c);
+    *us_new = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count() / reps;
+    t0 = std::chrono::steady_clock::now();
+    for (int r = 0; r < reps; ++r) {
+        xyzz acc = xyzz_from_mem(gs[G - 1]);
+        for (int g = (int)G - 2; g >= 0; --g) {
+            for (u32 k = 0; k < c; ++k) acc = xyzz_dbl<C>(acc);
+            acc = xyzz_add<C>(acc, xyzz_from_mem(gs[g]));
+        }
+        *out_old = xyzz_to_abi_jacobian<C>(acc);
+    }
+    *us_old = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count() / reps;
+}
+
 extern "C" {
+void host_window_combine_check(int curve, const void *pts, unsigned G, unsigned c, void *out_new, void *out_old, double *us) {
+    if (curve == 0) window_combine<0>((const affine256 *)pts, G, c, (jacobian256 *)out_new, (jacobian256 *)out_old, us, us + 1);
+    else window_combine<1>((const affine256 *)pts, G, c, (jacobian256 *)out_new, (jacobian256 *)out_old, us, us + 1);
+}
 void host_field_op(int field, int op, const void *a, const void *b, void *out, size_t n) {
     for (size_t i = 0; i < n; ++i) {
         if (field == 0) field_op<0>(op, (const fe256 *)a + i, (const fe256 *)b + i, (fe256 *)out + i);

@@ -21,7 +21,7 @@ CID = {"pallas": 0, "vesta": 1}
 @pytest.fixture(scope="module")
 def host():
     src = os.path.join(CSRC, "tools", "host_check.cpp")
-    deps = [src] + [os.path.join(CSRC, f) for f in ("field.h", "ec.h", "field_consts.h", "glv_host.h", "glv_consts.h")]
+    deps = [src] + [os.path.join(CSRC, f) for f in ("field.h", "ec.h", "field_consts.h", "glv_host.h", "glv_consts.h", "host_combine.h")]
     if not os.path.exists(SO) or os.path.getmtime(SO) < max(os.path.getmtime(d) for d in deps):
         os.makedirs(os.path.dirname(SO), exist_ok=True)
         subprocess.check_call(["g++", "-O2", "-std=c++17", "-DREEF_BOUNDS", "-shared", "-fPIC", src, "-o", SO])
@@ -31,6 +31,7 @@ def host():
     lib.host_ec_op.argtypes = [ctypes.c_int, ctypes.c_int, vp, vp, vp, vp, ctypes.c_size_t]
     lib.host_accumulate.argtypes = [ctypes.c_int, vp, vp, ctypes.c_size_t, vp, vp, vp]
     lib.host_pack_roundtrip.argtypes = [vp, vp]
+    lib.host_window_combine_check.argtypes = [ctypes.c_int, vp, ctypes.c_uint, ctypes.c_uint, vp, vp, vp]
     lib.host_glv_split.argtypes = [ctypes.c_int, vp, vp]
     lib.host_glv_phi.argtypes = [ctypes.c_int, vp, vp]
     return lib
@@ -141,6 +142,59 @@ def test_accumulate_chain_bounds(name, host, cref):
     host.host_accumulate(cid, two.ctypes.data, np.array([0, 0], dtype=np.uint8).ctypes.data, 2, jac.ctypes.data, aff.ctypes.data, comp.ctypes.data)
     p7 = C.affine_from_bytes(pts[7].tobytes())
     assert cref.compress(cid, jac) == C.compress(C.add(p7, p7))
+
+
+@pytest.mark.parametrize("name", ["pallas", "vesta"])
+def test_window_combine_on_the_host(name, host, cref):
+    """host_combine.h -- the window combine of a plain key on four 64-bit limbs, what the library runs on a host core since round 6 -- against
+    ec.h's own chain on the same window sums and against the big-integer oracle: sum_g 2^(c*g) * S_g for the plans the engine picks (c = 8 ... 16,
+    G = ceil(255 / c)), with empty windows, an empty top window, a window that equals the running sum (the doubling branch of the addition), one that
+    cancels it (the identity in mid-chain) and an all-empty input.  The window sums reach it in the engine's memory form, un-normalised limbs included."""
+    cid = CID[name]
+    C = CURVES[name]
+
+    def to_row(pt):
+        return np.frombuffer(C.affine_to_bytes(pt), dtype=np.uint64)
+
+    def run(sums, c):                                  # sums: per window a pair of affine points (None = identity) whose sum is the window's
+        G = len(sums)
+        pts = np.zeros((2 * G, 8), dtype=np.uint64)
+        for g, (a, b) in enumerate(sums):
+            pts[2 * g], pts[2 * g + 1] = to_row(a), to_row(b)
+        new, old, us = np.zeros(12, dtype=np.uint64), np.zeros(12, dtype=np.uint64), np.zeros(2)
+        host.host_window_combine_check(cid, pts.ctypes.data, G, c, new.ctypes.data, old.ctypes.data, us.ctypes.data)
+        want = None
+        for g in reversed(range(G)):
+            for _ in range(c):
+                want = C.add(want, want)
+            want = C.add(want, C.add(sums[g][0], sums[g][1]))
+        assert cref.compress(cid, new) == C.compress(want), ("host_combine.h", c, G)
+        assert cref.compress(cid, old) == C.compress(want), ("ec.h", c, G)
+        if want is None:
+            assert not new.any()                       # the identity is (0, 0, 0) at the ABI
+        return us
+
+    base = cref.gen_bases_ap(cid, 41, 3, 80)
+    P = [C.affine_from_bytes(base[i].tobytes()) for i in range(80)]
+    for c in (8, 11, 13, 16):
+        G = (255 + c - 1) // c
+        sums = [(P[2 * g], P[2 * g + 1]) for g in range(G)]
+        sums[1] = (None, None)                         # an empty window
+        sums[2] = (P[5], None)                         # a single point (ZZ = 1)
+        sums[3] = (None, P[6])
+        us = run(sums, c)
+        sums[G - 1] = (None, None)                     # nothing in the top window: the chain starts from the identity
+        sums[G - 2] = (P[9], C.neg(P[9]))              # a pair that cancels inside a window
+        run(sums, c)
+    c = 8
+    top = C.add(P[0], P[1])
+    shifted = top
+    for _ in range(c):
+        shifted = C.add(shifted, shifted)
+    run([(P[7], None), (shifted, None), (P[0], P[1])], c)            # window 1 equals 2^c * (window 2): the addition's doubling branch
+    run([(P[7], None), (C.neg(shifted), None), (P[0], P[1])], c)     # ... and its negative: the identity in mid-chain, the chain goes on from P[7]
+    run([(None, None)] * 4, c)
+    print(f"{name}: window combine c = 16, G = 16: {us[0]:.0f} us on four 64-bit limbs, {us[1]:.0f} us through ec.h (g++ -O2 with bound tracking)")
 
 
 @pytest.mark.parametrize("name", ["pallas", "vesta"])
