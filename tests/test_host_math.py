@@ -194,6 +194,16 @@ def test_window_combine_on_the_host(name, host, cref):
     run([(P[7], None), (shifted, None), (P[0], P[1])], c)            # window 1 equals 2^c * (window 2): the addition's doubling branch
     run([(P[7], None), (C.neg(shifted), None), (P[0], P[1])], c)     # ... and its negative: the identity in mid-chain, the chain goes on from P[7]
     run([(None, None)] * 4, c)
+    rng = SplitMix64(77 + cid)                         # random plans: any window width the engine may pick, random empty windows and single points
+    for _ in range(24):
+        c = 5 + rng.next() % 13
+        G = (255 + c - 1) // c
+        sums = []
+        for g in range(G):
+            kind = rng.next() % 5
+            a, b = P[rng.next() % 80], P[rng.next() % 80]
+            sums.append([(a, b), (a, None), (None, b), (None, None), (a, a)][kind])      # (a, a): the mixed addition's own doubling branch inside a window
+        run(sums, c)
     print(f"{name}: window combine c = 16, G = 16: {us[0]:.0f} us on four 64-bit limbs, {us[1]:.0f} us through ec.h (g++ -O2 with bound tracking)")
 
 
